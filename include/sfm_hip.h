@@ -1,0 +1,113 @@
+/* C ABI of libsfm_hip.so: the MI355X (gfx950) implementation of the robust-estimation hot
+ * path of the Structure-from-Motion reference pipeline.
+ *
+ * The reference exposes this path as Python functions, not as an FFI; each entry point
+ * below names the reference function (file:line under the reference checkout) whose
+ * arithmetic it replaces.  The Python package structure-from-motion_amd/sfm_hip binds these
+ * with ctypes and keeps the reference's function names and signatures on top.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer unless the parameter comment says "host".
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only
+ *    enqueue work; nothing here synchronises with the host.
+ *  - Return value: 0 on success, otherwise a hipError_t value or SFM_EINVAL for rejected
+ *    arguments; sfm_hip_error_string() turns it into text.
+ *  - A correspondence is (x1, y1, x2, y2): K-normalised image coordinates of one match in
+ *    view 1 and view 2, third homogeneous coordinate 1; `corr` is an array [n][4].
+ *  - A hypothesis is a row of 12 int32 indices into `corr`: columns 0-7 feed the 8-point
+ *    essential-matrix solver, columns 8-11 the 4-point homography solver
+ *    (src/ransac_algorithm.py:94 and :116 draw them in this order).
+ *  - 3x3 matrices are row-major [9]; cameras are row-major 3x4 [12].
+ */
+#ifndef SFM_HIP_H
+#define SFM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_EINVAL 100001
+
+const char* sfm_hip_error_string(int code);
+int sfm_hip_abi_version(void);
+
+/* Fused minimal solvers + inlier counting for nb hypotheses.
+ * Replaces one pass of the loop body src/ransac_algorithm.py:94-102 and :116-121
+ * (estimate_F_DLT :216-263, enforce_essential :176-190, epipolar_errors :193-213,
+ * estimate_H_DLT :266-293, get_inlier_mask_H :296-329) for every hypothesis.
+ * thr_e = err_threshold, thr_h = 3*err_threshold.  count_e/count_h: int32[nb]. */
+int sfm_eh_score_f64(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
+                     int32_t* count_e, int32_t* count_h, void* stream);
+
+/* The models themselves: F_out (estimate_F_DLT, :216-263, before the singular values are
+ * replaced), E_out (after enforce_essential, :176-190) and H_out (estimate_H_DLT, :266-293),
+ * each double[nb][9] or NULL.  Same solvers as sfm_eh_score_f64. */
+int sfm_eh_models_f64(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double* F_out, double* E_out,
+                      double* H_out, void* stream);
+
+/* Inlier mask (uint8[n], 0/1) and count (int32[1], may be NULL) of one essential matrix:
+ * the symmetric epipolar test of src/ransac_algorithm.py:98-102 / :133-138. */
+int sfm_epipolar_mask_f64(const double* E, const double* corr, int32_t n, double thr, uint8_t* mask, int32_t* count,
+                          void* stream);
+
+/* Inlier mask and count of one homography: src/ransac_algorithm.py:296-329. */
+int sfm_transfer_mask_f64(const double* H, const double* corr, int32_t n, double thr, uint8_t* mask, int32_t* count,
+                          void* stream);
+
+/* Four motion candidates of an essential matrix, P2s double[4][12]:
+ * src/ransac_algorithm.py:422-435 (SVD, determinant sign fix, [UWVt|+-u3], [UW'Vt|+-u3]). */
+int sfm_essential_candidates_f64(const double* E, double* P2s, void* stream);
+
+/* Chirality counts of four candidate second cameras over the correspondences selected by
+ * `mask` (NULL = all): DLT triangulation against P1=[I|0] and the test
+ * (P2 X)_z > 0 and (P1 X)_z > 0 of src/chirality_check.py:22-28 and :39-60.
+ * counts: int32[4] (overwritten). */
+int sfm_chirality4_f64(const double* P2s, const double* corr, const uint8_t* mask, int32_t n, int32_t* counts,
+                       void* stream);
+
+/* Homography -> two (R,t) solutions, src/ransac_algorithm.py:332-403 including the sign vote
+ * over all n correspondences (:359-361); H itself is not modified.
+ * out: double[42] = R1[9] t1[3] R2[9] t2[3] Ea[9] Eb[9] with E = [t]x R (:129-130). */
+int sfm_homography_to_rt_f64(const double* H, const double* corr, int32_t n, double* out, void* stream);
+
+/* DLT triangulation of m points, src/utils.py:17-36.  P1, P2: double[12]; x1, x2: the first two
+ * rows of the 3xM point arrays, row stride ld doubles; X: double[4][m] (row-major, last row 1). */
+int sfm_triangulate_f64(const double* P1, const double* P2, const double* x1, const double* x2, int32_t m, int64_t ld,
+                        double* X, void* stream);
+
+/* Packs one camera's 2D-3D correspondences for the translation stages:
+ * pts[j] = (R X_j, x_j) = double[6], with X promoted to double exactly as `R @ X` does in
+ * src/estimate_translation.py:98,123 and src/refine_translation.py:125.
+ * R: double[9]; X: [3][m] float32 (x_is_f64 = 0; what find_correspondences returns,
+ * src/utils.py:90) or float64 (x_is_f64 = 1); x: double[3][m]. */
+int sfm_pack_points_f64(const double* R, const void* X, int32_t x_is_f64, const double* x, int32_t m, double* pts,
+                        void* stream);
+
+/* 2-point translation RANSAC for ncam cameras in one launch:
+ * src/estimate_translation.py:62-75 (estimate_T_2point :80-106, count_inliers :109-129).
+ * pts: packed points of all cameras back to back; cam_off (HOST, int64[ncam+1]): first point
+ * of each camera; idx: int32[ncam][nb][2], indices local to the camera; thr = 4*pixel/fx.
+ * counts: int32[ncam][nb] workspace/output; best: uint64[ncam] = (count << 32) | (0xFFFFFFFF - index)
+ * of the first maximum; T_best: double[ncam][3], the winner's translation (unspecified when
+ * the count is 0: the reference returns None then). */
+int sfm_t_ransac_f64(const double* pts, const int64_t* cam_off, int32_t ncam, const int32_t* idx, int64_t nb, double thr,
+                     int32_t* counts, uint64_t* best, double* T_best, void* stream);
+
+/* Translations of given samples only: T_out double[nb][3] (estimate_T_2point, :80-106). */
+int sfm_t_models_f64(const double* pts, int32_t m, const int32_t* idx, int64_t nb, double* T_out, void* stream);
+
+/* Fixed-damping Levenberg-Marquardt on T for ncam cameras in one launch:
+ * src/refine_translation.py:57-104 with compute_reprojection_error :107-132, ComputeUpdate
+ * :135-155 and projection_derivatives_wrt_T :158-200, including the reference's pairing of the
+ * residual vector [all dx | all dy] with the interleaved Jacobian rows.
+ * K: double[9]; T0: double[ncam][3]; work: double[2 * total_points] scratch;
+ * T_out: double[ncam][3]; history: double[ncam][iters][3] or NULL. */
+int sfm_lm_translation_f64(const double* K, const double* pts, const int64_t* cam_off, int32_t ncam, const double* T0,
+                           int32_t iters, double mu, double* work, double* T_out, double* history, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,668 @@
+// HIP kernels and C ABI of libsfm_hip.so (gfx950 / MI355X only).
+//
+// Layout of the hot kernels: one hypothesis per lane.  A lane gathers its minimal sample,
+// solves the model in registers (sfm_math.hpp) and then walks the correspondence array.
+// The correspondence index is wave-uniform, so the compiler fetches each correspondence
+// with scalar loads into SGPRs; the VALU only executes the residual arithmetic, with the
+// model in VGPRs and the point as the scalar operand of each instruction.  Counts are
+// accumulated per lane (compare + add-with-carry), so no cross-lane reduction is needed.
+// Nothing is GEMM shaped; there is no MFMA in this library.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sfm_hip.h"
+#include "sfm_math.hpp"
+
+using namespace sfm;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxCams = 64;
+
+struct CamOffsets {
+  int64_t off[kMaxCams + 1];
+};
+
+template <typename T>
+__device__ __forceinline__ void gather_samples(const double4* __restrict__ corr, const int32_t* __restrict__ row, T (&p8)[8][4],
+                                               T (&p4)[4][4]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const double4 c = corr[row[i]];
+    p8[i][0] = T(c.x); p8[i][1] = T(c.y); p8[i][2] = T(c.z); p8[i][3] = T(c.w);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double4 c = corr[row[8 + i]];
+    p4[i][0] = T(c.x); p4[i][1] = T(c.y); p4[i][2] = T(c.z); p4[i][3] = T(c.w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// E/H hypothesis scoring.  grid = (hypothesis tiles, point splits).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void eh_score_kernel(const double4* __restrict__ corr, int n, const int32_t* __restrict__ idx,
+                                                          long long nb, double two_thr_e2, double thr_h2, int* __restrict__ count_e,
+                                                          int* __restrict__ count_h, int points_per_split, int use_atomics) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long h = gid < nb ? gid : nb - 1;  // tail lanes repeat the last hypothesis: every lane stays active
+  double E[9], H[9];
+  {
+    double p8[8][4], p4[4][4];
+    gather_samples<double>(corr, idx + 12 * h, p8, p4);
+    solve_E8<double>(p8, E);
+    solve_H4<double>(p4, H);
+  }
+  const int j0 = blockIdx.y * points_per_split;
+  const int j1 = min(n, j0 + points_per_split);
+  int ce = 0, ch = 0;
+#pragma unroll 4
+  for (int j = j0; j < j1; ++j) {
+    const double4 p = corr[j];
+    ce += epipolar_inlier<double>(E, p.x, p.y, p.z, p.w, two_thr_e2) ? 1 : 0;
+    ch += transfer_inlier<double>(H, p.x, p.y, p.z, p.w, thr_h2) ? 1 : 0;
+  }
+  if (gid < nb) {
+    if (use_atomics) {
+      atomicAdd(count_e + gid, ce);
+      atomicAdd(count_h + gid, ch);
+    } else {
+      count_e[gid] = ce;
+      count_h[gid] = ch;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void eh_models_kernel(const double4* __restrict__ corr, const int32_t* __restrict__ idx, long long nb,
+                                                           double* __restrict__ F_out, double* __restrict__ E_out,
+                                                           double* __restrict__ H_out) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long h = gid < nb ? gid : nb - 1;
+  double F[9], E[9], H[9];
+  double p8[8][4], p4[4][4];
+  gather_samples<double>(corr, idx + 12 * h, p8, p4);
+  solve_E8<double>(p8, E, F);
+  solve_H4<double>(p4, H);
+  if (gid < nb) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      if (F_out) F_out[9 * gid + i] = F[i];
+      if (E_out) E_out[9 * gid + i] = E[i];
+      if (H_out) H_out[9 * gid + i] = H[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Record-event kernels: one point per lane.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_count(bool flag) {
+  // per-wave ballot/popcount, then one LDS add per wave
+  __shared__ int wave_sum[kBlock / 64];
+  const unsigned long long b = __ballot(flag);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_sum[wave] = __popcll(b);
+  __syncthreads();
+  int total = 0;
+  if (threadIdx.x == 0) {
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) total += wave_sum[w];
+  }
+  __syncthreads();
+  return total;  // valid in thread 0
+}
+
+template <bool kEpipolar>
+__global__ __launch_bounds__(kBlock) void mask_kernel(const double* __restrict__ M, const double4* __restrict__ corr, int n, double thr_arg,
+                                                      uint8_t* __restrict__ mask, int* __restrict__ count) {
+  double m[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) m[i] = M[i];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  bool in = false;
+  if (j < n) {
+    const double4 p = corr[j];
+    in = kEpipolar ? epipolar_inlier<double>(m, p.x, p.y, p.z, p.w, thr_arg) : transfer_inlier<double>(m, p.x, p.y, p.z, p.w, thr_arg);
+    mask[j] = in ? 1 : 0;
+  }
+  const int c = block_count(in);
+  if (count && threadIdx.x == 0 && c) atomicAdd(count, c);
+}
+
+__global__ void essential_candidates_kernel(const double* __restrict__ E, double* __restrict__ P2s) {
+  double e[9], P[4][12];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) e[i] = E[i];
+  essential_candidates<double>(e, P);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 12; ++i) P2s[12 * c + i] = P[c][i];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void chirality4_kernel(const double* __restrict__ P2s, const double4* __restrict__ corr,
+                                                            const uint8_t* __restrict__ mask, int n, int* __restrict__ counts) {
+  const double P1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = gid < n ? gid : n - 1;
+  const bool live = gid < n && (mask == nullptr || mask[j] != 0);
+  const double4 p = corr[j];
+  for (int c = 0; c < 4; ++c) {
+    double P2[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) P2[i] = P2s[12 * c + i];
+    double X[4];
+    triangulate_point<double>(P1, P2, p.x, p.y, p.z, p.w, X);
+    // (P2 X)_z and (P1 X)_z with X = v / v_3, as in src/chirality_check.py:56
+    const double z2 = ((P2[8] * X[0] + P2[9] * X[1]) + P2[10] * X[2]) + P2[11] * X[3];
+    const double z1 = ((P1[8] * X[0] + P1[9] * X[1]) + P1[10] * X[2]) + P1[11] * X[3];
+    const int cnt = block_count(live && z2 > 0.0 && z1 > 0.0);
+    if (threadIdx.x == 0 && cnt) atomicAdd(counts + c, cnt);
+  }
+}
+
+// one block: sign vote over all points, then thread 0 decomposes
+__global__ __launch_bounds__(1024) void homography_to_rt_kernel(const double* __restrict__ H, const double4* __restrict__ corr, int n,
+                                                                double* __restrict__ out) {
+  __shared__ int votes;
+  if (threadIdx.x == 0) votes = 0;
+  __syncthreads();
+  double h[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) h[i] = H[i];
+  int mine = 0;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const double4 p = corr[j];
+    // sum(x2 * (H @ x1)) > 0, src/ransac_algorithm.py:359
+    const double hx = (h[0] * p.x + h[1] * p.y) + h[2];
+    const double hy = (h[3] * p.x + h[4] * p.y) + h[5];
+    const double hz = (h[6] * p.x + h[7] * p.y) + h[8];
+    const double s = (p.z * hx + p.w * hy) + hz;
+    mine += s > 0.0 ? 1 : 0;
+  }
+  atomicAdd(&votes, mine);
+  __syncthreads();
+  const bool flip = (double)votes < (double)n / 2.0;
+  double R1[3][3], R2[3][3], t1[3], t2[3], Ea[9], Eb[9];
+  homography_decompose<double>(h, flip, R1, t1, R2, t2);
+  skew_times<double>(t1, R1, Ea);
+  skew_times<double>(t2, R2, Eb);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      out[i] = R1[i / 3][i % 3];
+      out[12 + i] = R2[i / 3][i % 3];
+      out[24 + i] = Ea[i];
+      out[33 + i] = Eb[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      out[9 + i] = t1[i];
+      out[21 + i] = t2[i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void triangulate_kernel(const double* __restrict__ P1g, const double* __restrict__ P2g,
+                                                             const double* __restrict__ x1, const double* __restrict__ x2, int m,
+                                                             long long ld, double* __restrict__ X) {
+  double P1[12], P2[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    P1[i] = P1g[i];
+    P2[i] = P2g[i];
+  }
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = gid < m ? gid : m - 1;
+  double out[4];
+  triangulate_point<double>(P1, P2, x1[j], x1[ld + j], x2[j], x2[ld + j], out);
+  if (gid < m) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) X[(long long)i * m + j] = out[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Translation stages
+// ---------------------------------------------------------------------------------------
+template <typename TX>
+__global__ __launch_bounds__(kBlock) void pack_points_kernel(const double* __restrict__ R, const TX* __restrict__ X,
+                                                             const double* __restrict__ x, int m, double* __restrict__ pts) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const double X0 = (double)X[j], X1 = (double)X[m + j], X2 = (double)X[2LL * m + j];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pts[6LL * j + i] = (R[3 * i] * X0 + R[3 * i + 1] * X1) + R[3 * i + 2] * X2;
+  pts[6LL * j + 3] = x[j];
+  pts[6LL * j + 4] = x[m + j];
+  pts[6LL * j + 5] = x[2LL * m + j];
+}
+
+__device__ __forceinline__ void load_t_sample(const double* __restrict__ pts, const int32_t* __restrict__ pair, double (&x)[2][3],
+                                              double (&r)[2][3]) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const double* p = pts + 6LL * pair[k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      r[k][i] = p[i];
+      x[k][i] = p[3 + i];
+    }
+  }
+}
+
+// grid = (hypothesis tiles, cameras, point splits)
+__global__ __launch_bounds__(kBlock) void t_score_kernel(const double* __restrict__ pts_all, CamOffsets offs, const int32_t* __restrict__ idx,
+                                                         long long nb, double thr2, int* __restrict__ counts, int points_per_split,
+                                                         int use_atomics) {
+  const int cam = blockIdx.y;
+  const double* __restrict__ pts = pts_all + 6 * offs.off[cam];
+  const int m = (int)(offs.off[cam + 1] - offs.off[cam]);
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long h = gid < nb ? gid : nb - 1;
+  const int32_t* pair = idx + 2 * ((long long)cam * nb + h);
+  double T[3];
+  {
+    double x[2][3], r[2][3];
+    load_t_sample(pts, pair, x, r);
+    solve_T2<double>(x, r, pair[0] == pair[1], T);
+  }
+  const int j0 = blockIdx.z * points_per_split;
+  const int j1 = min(m, j0 + points_per_split);
+  int c = 0;
+#pragma unroll 4
+  for (int j = j0; j < j1; ++j) {
+    const double* p = pts + 6LL * j;
+    c += reprojection_inlier<double>(T[0], T[1], T[2], p[0], p[1], p[2], p[3], p[4], thr2) ? 1 : 0;
+  }
+  if (gid < nb) {
+    int* dst = counts + (long long)cam * nb + gid;
+    if (use_atomics)
+      atomicAdd(dst, c);
+    else
+      *dst = c;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void t_models_kernel(const double* __restrict__ pts, const int32_t* __restrict__ idx, long long nb,
+                                                          double* __restrict__ T_out) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= nb) return;
+  double x[2][3], r[2][3], T[3];
+  load_t_sample(pts, idx + 2 * gid, x, r);
+  solve_T2<double>(x, r, idx[2 * gid] == idx[2 * gid + 1], T);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) T_out[3 * gid + i] = T[i];
+}
+
+// first maximum of counts[cam][0..nb): key = (count << 32) | (0xFFFFFFFF - index), max over keys
+__global__ __launch_bounds__(kBlock) void argmax_kernel(const int* __restrict__ counts, long long nb, unsigned long long* __restrict__ best) {
+  const int cam = blockIdx.y;
+  unsigned long long key = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long k = ((unsigned long long)(unsigned)counts[(long long)cam * nb + i] << 32) | (0xFFFFFFFFull - (unsigned long long)i);
+    key = k > key ? k : key;
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const unsigned long long o = __shfl_xor(key, s, 64);
+    key = o > key ? o : key;
+  }
+  if ((threadIdx.x & 63) == 0 && key) atomicMax(best + cam, key);
+}
+
+__global__ void t_winner_kernel(const double* __restrict__ pts_all, CamOffsets offs, const int32_t* __restrict__ idx, long long nb,
+                                const unsigned long long* __restrict__ best, double* __restrict__ T_best) {
+  const int cam = blockIdx.x;
+  const unsigned long long key = best[cam];
+  const long long i = (long long)(0xFFFFFFFFull - (key & 0xFFFFFFFFull));
+  const long long h = (key == 0 || i >= nb) ? 0 : i;
+  const double* pts = pts_all + 6 * offs.off[cam];
+  const int32_t* pair = idx + 2 * ((long long)cam * nb + h);
+  double x[2][3], r[2][3], T[3];
+  load_t_sample(pts, pair, x, r);
+  solve_T2<double>(x, r, pair[0] == pair[1], T);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) T_best[3 * cam + k] = T[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Levenberg-Marquardt on T, one workgroup per camera, all iterations in one launch.
+// ---------------------------------------------------------------------------------------
+constexpr int kLmBlock = 1024;
+
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* sh /* [NV][16] */) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v[k] += __shfl_xor(v[k], s, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sh[k * 16 + wave] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[k * 16 + w];
+    v[k] = t;  // every thread holds the same total, summed in the same order
+  }
+}
+
+__global__ __launch_bounds__(kLmBlock) void lm_kernel(const double* __restrict__ Kg, const double* __restrict__ pts_all, CamOffsets offs,
+                                                      const double* __restrict__ T0, int iters, double mu, double* __restrict__ work,
+                                                      double* __restrict__ T_out, double* __restrict__ history) {
+  __shared__ double sh[10 * 16];
+  const int cam = blockIdx.x;
+  const double* __restrict__ pts = pts_all + 6 * offs.off[cam];
+  const int m = (int)(offs.off[cam + 1] - offs.off[cam]);
+  double* __restrict__ r = work + 2 * offs.off[cam];  // [dx_0..dx_{m-1} | dy_0..dy_{m-1}]
+  double K[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) K[i] = Kg[i];
+  double T[3] = {T0[3 * cam], T0[3 * cam + 1], T0[3 * cam + 2]};
+  for (int it = 0; it < iters; ++it) {
+    // residuals of the current T (src/refine_translation.py:125-132)
+    double err[1] = {0.0};
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+      const double* p = pts + 6LL * j;
+      const double pz = p[2] + T[2];
+      const double dx = (p[0] + T[0]) / pz - p[3];
+      const double dy = (p[1] + T[1]) / pz - p[4];
+      r[j] = dx;
+      r[m + j] = dy;
+      err[0] += dx * dx + dy * dy;
+    }
+    __syncthreads();  // r is read across threads below (same workgroup, global memory)
+    __threadfence_block();
+    // normal equations: C = J^T J (6 unique), c = J^T r with Jacobian row k paired with r[k]
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+      const double* p = pts + 6LL * j;
+      const double Xc[3] = {p[0] + T[0], p[1] + T[1], p[2] + T[2]};
+      double xp[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) xp[a] = (K[3 * a] * Xc[0] + K[3 * a + 1] * Xc[1]) + K[3 * a + 2] * Xc[2];
+      const double inv = 1.0 / (xp[2] * xp[2]);
+      double Ju[3], Jv[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        Ju[i] = (xp[2] * K[i] - xp[0] * K[6 + i]) * inv;
+        Jv[i] = (xp[2] * K[3 + i] - xp[1] * K[6 + i]) * inv;
+      }
+      const double ru = r[2 * j], rv = r[2 * j + 1];
+      acc[0] += Ju[0] * Ju[0] + Jv[0] * Jv[0];
+      acc[1] += Ju[0] * Ju[1] + Jv[0] * Jv[1];
+      acc[2] += Ju[0] * Ju[2] + Jv[0] * Jv[2];
+      acc[3] += Ju[1] * Ju[1] + Jv[1] * Jv[1];
+      acc[4] += Ju[1] * Ju[2] + Jv[1] * Jv[2];
+      acc[5] += Ju[2] * Ju[2] + Jv[2] * Jv[2];
+      acc[6] += Ju[0] * ru + Jv[0] * rv;
+      acc[7] += Ju[1] * ru + Jv[1] * rv;
+      acc[8] += Ju[2] * ru + Jv[2] * rv;
+    }
+    double tot[10];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tot[i] = acc[i];
+    tot[9] = err[0];
+    block_sum<10>(tot, sh);
+    // delta = solve(-C, c) with C = J^T J + mu I: Gaussian elimination with partial pivoting
+    double A[3][4] = {{-(tot[0] + mu), -tot[1], -tot[2], tot[6]},
+                      {-tot[1], -(tot[3] + mu), -tot[4], tot[7]},
+                      {-tot[2], -tot[4], -(tot[5] + mu), tot[8]}};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+      for (int i = k + 1; i < 3; ++i) {
+        if (fabs(A[i][k]) > fabs(A[k][k])) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const double t = A[k][c];
+            A[k][c] = A[i][c];
+            A[i][c] = t;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = k + 1; i < 3; ++i) {
+        const double f = A[i][k] / A[k][k];
+#pragma unroll
+        for (int c = k; c < 4; ++c) A[i][c] -= f * A[k][c];
+      }
+    }
+    double d[3];
+    d[2] = A[2][3] / A[2][2];
+    d[1] = (A[1][3] - A[1][2] * d[2]) / A[1][1];
+    d[0] = (A[0][3] - A[0][1] * d[1] - A[0][2] * d[2]) / A[0][0];
+    const double Tn[3] = {T[0] + d[0], T[1] + d[1], T[2] + d[2]};
+    double en[1] = {0.0};
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+      const double* p = pts + 6LL * j;
+      const double pz = p[2] + Tn[2];
+      const double dx = (p[0] + Tn[0]) / pz - p[3];
+      const double dy = (p[1] + Tn[1]) / pz - p[4];
+      en[0] += dx * dx + dy * dy;
+    }
+    block_sum<1>(en, sh);
+    if (en[0] < tot[9]) {
+      T[0] = Tn[0];
+      T[1] = Tn[1];
+      T[2] = Tn[2];
+    }
+    if (history && threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) history[((long long)cam * iters + it) * 3 + k] = T[k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) T_out[3 * cam + k] = T[k];
+  }
+}
+
+// hipGetLastError() reports the last error of ANY earlier HIP call on this thread (other
+// libraries in the process included), so every entry point clears it before it launches.
+inline void clear_stale_error() { (void)hipGetLastError(); }
+inline int check_launch() { return (int)hipGetLastError(); }
+
+inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Splits the point range when there are too few hypothesis tiles to fill 256 CUs.
+inline int choose_splits(long long tiles, int npoints) {
+  const long long want = 2048;
+  if (tiles >= want) return 1;
+  long long s = (want + tiles - 1) / tiles;
+  const long long max_s = (npoints + 255) / 256;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  if (s > 65535) s = 65535;
+  return (int)s;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sfm_hip_error_string(int code) {
+  if (code == SFM_EINVAL) return "sfm_hip: invalid argument";
+  return hipGetErrorString((hipError_t)code);
+}
+
+int sfm_hip_abi_version(void) { return 1; }
+
+int sfm_eh_score_f64(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, int32_t* count_e,
+                     int32_t* count_h, void* stream) {
+  clear_stale_error();
+  if (!corr || !idx || !count_e || !count_h || n <= 0 || nb < 0) return SFM_EINVAL;
+  if (nb == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const long long tiles = (nb + kBlock - 1) / kBlock;
+  if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
+  const int splits = choose_splits(tiles, n);
+  const int pps = div_up(n, splits);
+  if (splits > 1) {
+    hipError_t e = hipMemsetAsync(count_e, 0, sizeof(int32_t) * nb, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(count_h, 0, sizeof(int32_t) * nb, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  eh_score_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, n, idx, nb, 2.0 * thr_e * thr_e, thr_h * thr_h,
+                                                                    count_e, count_h, pps, splits > 1);
+  return check_launch();
+}
+
+int sfm_eh_models_f64(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double* F_out, double* E_out, double* H_out,
+                      void* stream) {
+  clear_stale_error();
+  if (!corr || !idx || n <= 0 || nb < 0) return SFM_EINVAL;
+  if (nb == 0) return 0;
+  eh_models_kernel<<<div_up(nb, kBlock), kBlock, 0, (hipStream_t)stream>>>((const double4*)corr, idx, nb, F_out, E_out, H_out);
+  return check_launch();
+}
+
+static int mask_common(bool epi, const double* M, const double* corr, int32_t n, double thr, uint8_t* mask, int32_t* count, void* stream) {
+  clear_stale_error();
+  if (!M || !corr || !mask || n < 0) return SFM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (count) {
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (n == 0) return 0;
+  if (epi)
+    mask_kernel<true><<<div_up(n, kBlock), kBlock, 0, st>>>(M, (const double4*)corr, n, 2.0 * thr * thr, mask, count);
+  else
+    mask_kernel<false><<<div_up(n, kBlock), kBlock, 0, st>>>(M, (const double4*)corr, n, thr * thr, mask, count);
+  return check_launch();
+}
+
+int sfm_epipolar_mask_f64(const double* E, const double* corr, int32_t n, double thr, uint8_t* mask, int32_t* count, void* stream) {
+  clear_stale_error();
+  return mask_common(true, E, corr, n, thr, mask, count, stream);
+}
+
+int sfm_transfer_mask_f64(const double* H, const double* corr, int32_t n, double thr, uint8_t* mask, int32_t* count, void* stream) {
+  clear_stale_error();
+  return mask_common(false, H, corr, n, thr, mask, count, stream);
+}
+
+int sfm_essential_candidates_f64(const double* E, double* P2s, void* stream) {
+  clear_stale_error();
+  if (!E || !P2s) return SFM_EINVAL;
+  essential_candidates_kernel<<<1, 64, 0, (hipStream_t)stream>>>(E, P2s);
+  return check_launch();
+}
+
+int sfm_chirality4_f64(const double* P2s, const double* corr, const uint8_t* mask, int32_t n, int32_t* counts, void* stream) {
+  clear_stale_error();
+  if (!P2s || !corr || !counts || n < 0) return SFM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), st);
+  if (e != hipSuccess) return (int)e;
+  if (n == 0) return 0;
+  chirality4_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(P2s, (const double4*)corr, mask, n, counts);
+  return check_launch();
+}
+
+int sfm_homography_to_rt_f64(const double* H, const double* corr, int32_t n, double* out, void* stream) {
+  clear_stale_error();
+  if (!H || !corr || !out || n < 0) return SFM_EINVAL;
+  homography_to_rt_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(H, (const double4*)corr, n, out);
+  return check_launch();
+}
+
+int sfm_triangulate_f64(const double* P1, const double* P2, const double* x1, const double* x2, int32_t m, int64_t ld, double* X,
+                        void* stream) {
+  clear_stale_error();
+  if (!P1 || !P2 || !x1 || !x2 || !X || m < 0 || ld < m) return SFM_EINVAL;
+  if (m == 0) return 0;
+  triangulate_kernel<<<div_up(m, kBlock), kBlock, 0, (hipStream_t)stream>>>(P1, P2, x1, x2, m, ld, X);
+  return check_launch();
+}
+
+int sfm_pack_points_f64(const double* R, const void* X, int32_t x_is_f64, const double* x, int32_t m, double* pts, void* stream) {
+  clear_stale_error();
+  if (!R || !X || !x || !pts || m < 0) return SFM_EINVAL;
+  if (m == 0) return 0;
+  if (x_is_f64)
+    pack_points_kernel<double><<<div_up(m, kBlock), kBlock, 0, (hipStream_t)stream>>>(R, (const double*)X, x, m, pts);
+  else
+    pack_points_kernel<float><<<div_up(m, kBlock), kBlock, 0, (hipStream_t)stream>>>(R, (const float*)X, x, m, pts);
+  return check_launch();
+}
+
+static int fill_offsets(const int64_t* cam_off, int32_t ncam, CamOffsets* o) {
+  if (!cam_off || ncam <= 0 || ncam > kMaxCams) return SFM_EINVAL;
+  for (int i = 0; i <= ncam; ++i) {
+    o->off[i] = cam_off[i];
+    if (i && cam_off[i] < cam_off[i - 1]) return SFM_EINVAL;
+    if (i && cam_off[i] - cam_off[i - 1] > 0x7FFFFFFFLL) return SFM_EINVAL;
+  }
+  return 0;
+}
+
+int sfm_t_ransac_f64(const double* pts, const int64_t* cam_off, int32_t ncam, const int32_t* idx, int64_t nb, double thr, int32_t* counts,
+                     uint64_t* best, double* T_best, void* stream) {
+  clear_stale_error();
+  if (!pts || !idx || !counts || !best || !T_best || nb <= 0) return SFM_EINVAL;
+  CamOffsets offs;
+  int rc = fill_offsets(cam_off, ncam, &offs);
+  if (rc) return rc;
+  int mmax = 0;
+  for (int c = 0; c < ncam; ++c) {
+    const int m = (int)(offs.off[c + 1] - offs.off[c]);
+    if (m <= 0) return SFM_EINVAL;  // an empty camera has no sample to draw
+    mmax = m > mmax ? m : mmax;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const long long tiles = (nb + kBlock - 1) / kBlock;
+  if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
+  const int splits = choose_splits(tiles * ncam, mmax);
+  const int pps = div_up(mmax, splits);
+  hipError_t e;
+  if (splits > 1) {
+    e = hipMemsetAsync(counts, 0, sizeof(int32_t) * nb * ncam, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  e = hipMemsetAsync(best, 0, sizeof(uint64_t) * ncam, st);
+  if (e != hipSuccess) return (int)e;
+  t_score_kernel<<<dim3((unsigned)tiles, ncam, splits), kBlock, 0, st>>>(pts, offs, idx, nb, thr * thr, counts, pps, splits > 1);
+  rc = check_launch();
+  if (rc) return rc;
+  const int ablocks = (int)(tiles < 256 ? tiles : 256);
+  argmax_kernel<<<dim3(ablocks, ncam), kBlock, 0, st>>>(counts, nb, (unsigned long long*)best);
+  rc = check_launch();
+  if (rc) return rc;
+  t_winner_kernel<<<ncam, 64, 0, st>>>(pts, offs, idx, nb, (const unsigned long long*)best, T_best);
+  return check_launch();
+}
+
+int sfm_t_models_f64(const double* pts, int32_t m, const int32_t* idx, int64_t nb, double* T_out, void* stream) {
+  clear_stale_error();
+  if (!pts || !idx || !T_out || m <= 0 || nb < 0) return SFM_EINVAL;
+  if (nb == 0) return 0;
+  t_models_kernel<<<div_up(nb, kBlock), kBlock, 0, (hipStream_t)stream>>>(pts, idx, nb, T_out);
+  return check_launch();
+}
+
+int sfm_lm_translation_f64(const double* K, const double* pts, const int64_t* cam_off, int32_t ncam, const double* T0, int32_t iters,
+                           double mu, double* work, double* T_out, double* history, void* stream) {
+  clear_stale_error();
+  if (!K || !pts || !T0 || !work || !T_out || iters < 0) return SFM_EINVAL;
+  CamOffsets offs;
+  int rc = fill_offsets(cam_off, ncam, &offs);
+  if (rc) return rc;
+  lm_kernel<<<ncam, kLmBlock, 0, (hipStream_t)stream>>>(K, pts, offs, T0, iters, mu, work, T_out, history);
+  return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,177 @@
+"""Device-level operators: thin Python wrappers, one per C-ABI entry point.
+
+Inputs and outputs are torch CUDA tensors (device memory) unless a name ends in ``_host``.
+Everything is enqueued on torch's current stream; callers synchronise by reading results.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _capi as C
+
+
+def pack_corr(x1, x2):
+    """(3,N) K-normalised homogeneous points of two views -> host array [N][4] float64.
+
+    The kernels assume the third homogeneous coordinate is exactly 1 (it always is after
+    normalize_K of pixel coordinates whose third row is 1; reference src/utils.py:44-45)."""
+    x1 = np.asarray(x1, dtype=np.float64)
+    x2 = np.asarray(x2, dtype=np.float64)
+    if x1.shape[0] == 2:
+        x1 = np.vstack([x1, np.ones((1, x1.shape[1]))])
+    if x2.shape[0] == 2:
+        x2 = np.vstack([x2, np.ones((1, x2.shape[1]))])
+    if x1.shape != x2.shape or x1.shape[0] != 3:
+        raise ValueError("x1 and x2 must both be 3xN")
+    if not (np.all(x1[2] == 1.0) and np.all(x2[2] == 1.0)):
+        raise ValueError("the HIP path needs homogeneous points with third coordinate exactly 1")
+    return np.ascontiguousarray(np.stack([x1[0], x1[1], x2[0], x2[1]], axis=1))
+
+
+def _empty(shape, dtype):
+    torch = C.torch_cuda()
+    return torch.empty(shape, dtype=dtype, device="cuda")
+
+
+def eh_score(corr, idx, thr_e, thr_h, out=None):
+    """corr: float64 [N][4]; idx: int32 [B][12] -> (count_e, count_h) int32 [B]."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    n = corr.shape[0]
+    nb = idx.shape[0]
+    assert corr.dtype == torch.float64 and corr.is_contiguous() and corr.shape[1] == 4
+    assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.shape[1] == 12
+    if out is None:
+        ce = _empty((nb,), torch.int32)
+        ch = _empty((nb,), torch.int32)
+    else:
+        ce, ch = out
+    C.check(lib.sfm_eh_score_f64(C.dptr(corr), n, C.dptr(idx), nb, float(thr_e), float(thr_h), C.dptr(ce), C.dptr(ch), C.stream_ptr()))
+    return ce, ch
+
+
+def eh_models(corr, idx, want_F=False):
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    nb = idx.shape[0]
+    F = _empty((nb, 9), torch.float64) if want_F else None
+    E = _empty((nb, 9), torch.float64)
+    H = _empty((nb, 9), torch.float64)
+    C.check(lib.sfm_eh_models_f64(C.dptr(corr), corr.shape[0], C.dptr(idx), nb, C.dptr(F), C.dptr(E), C.dptr(H), C.stream_ptr()))
+    return (F, E, H) if want_F else (E, H)
+
+
+def epipolar_mask(E, corr, thr):
+    """E: float64 [9] device -> (mask uint8 [N], count int32 [1])."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    n = corr.shape[0]
+    mask = _empty((n,), torch.uint8)
+    count = _empty((1,), torch.int32)
+    C.check(lib.sfm_epipolar_mask_f64(C.dptr(E), C.dptr(corr), n, float(thr), C.dptr(mask), C.dptr(count), C.stream_ptr()))
+    return mask, count
+
+
+def transfer_mask(H, corr, thr):
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    n = corr.shape[0]
+    mask = _empty((n,), torch.uint8)
+    count = _empty((1,), torch.int32)
+    C.check(lib.sfm_transfer_mask_f64(C.dptr(H), C.dptr(corr), n, float(thr), C.dptr(mask), C.dptr(count), C.stream_ptr()))
+    return mask, count
+
+
+def essential_candidates(E):
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    P = _empty((4, 12), torch.float64)
+    C.check(lib.sfm_essential_candidates_f64(C.dptr(E), C.dptr(P), C.stream_ptr()))
+    return P
+
+
+def chirality4(P2s, corr, mask=None):
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    counts = _empty((4,), torch.int32)
+    C.check(lib.sfm_chirality4_f64(C.dptr(P2s), C.dptr(corr), C.dptr(mask), corr.shape[0], C.dptr(counts), C.stream_ptr()))
+    return counts
+
+
+def homography_to_rt(H, corr):
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    out = _empty((42,), torch.float64)
+    C.check(lib.sfm_homography_to_rt_f64(C.dptr(H), C.dptr(corr), corr.shape[0], C.dptr(out), C.stream_ptr()))
+    return out
+
+
+def triangulate(P1, P2, x1, x2):
+    """P1,P2: float64 [12]; x1,x2: float64 [>=2][M] contiguous rows -> X float64 [4][M]."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    m = x1.shape[1]
+    X = _empty((4, m), torch.float64)
+    C.check(lib.sfm_triangulate_f64(C.dptr(P1), C.dptr(P2), C.dptr(x1), C.dptr(x2), m, x1.stride(0), C.dptr(X), C.stream_ptr()))
+    return X
+
+
+def pack_points(R, X, x):
+    """R: float64 [9]; X: float32 or float64 [3][M]; x: float64 [3][M] -> pts float64 [M][6]."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    m = x.shape[1]
+    assert X.dtype in (torch.float32, torch.float64) and X.is_contiguous() and x.is_contiguous()
+    pts = _empty((m, 6), torch.float64)
+    C.check(lib.sfm_pack_points_f64(C.dptr(R), C.dptr(X), int(X.dtype == torch.float64), C.dptr(x), m, C.dptr(pts), C.stream_ptr()))
+    return pts
+
+
+def _offsets(cam_sizes):
+    off = np.zeros(len(cam_sizes) + 1, np.int64)
+    off[1:] = np.cumsum(cam_sizes)
+    return off
+
+
+def t_ransac(pts, cam_sizes, idx, thr):
+    """pts: float64 [sum M][6]; idx: int32 [ncam][B][2] -> (best uint64->int64 view [ncam], T_best [ncam][3], counts [ncam][B])."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    ncam, nb = idx.shape[0], idx.shape[1]
+    off = _offsets(cam_sizes)
+    counts = _empty((ncam, nb), torch.int32)
+    best = _empty((ncam,), torch.int64)
+    T = _empty((ncam, 3), torch.float64)
+    C.check(lib.sfm_t_ransac_f64(C.dptr(pts), C.hptr(off), ncam, C.dptr(idx), nb, float(thr), C.dptr(counts), C.dptr(best), C.dptr(T), C.stream_ptr()))
+    return best, T, counts
+
+
+def decode_best(best_host):
+    """uint64 keys (as int64) -> (count, index) arrays."""
+    k = np.asarray(best_host).astype(np.uint64)
+    count = (k >> np.uint64(32)).astype(np.int64)
+    index = (np.uint64(0xFFFFFFFF) - (k & np.uint64(0xFFFFFFFF))).astype(np.int64)
+    return count, index
+
+
+def t_models(pts, idx):
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    nb = idx.shape[0]
+    T = _empty((nb, 3), torch.float64)
+    C.check(lib.sfm_t_models_f64(C.dptr(pts), pts.shape[0], C.dptr(idx), nb, C.dptr(T), C.stream_ptr()))
+    return T
+
+
+def lm_translation(K, pts, cam_sizes, T0, iters, mu, want_history=False):
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    ncam = len(cam_sizes)
+    off = _offsets(cam_sizes)
+    work = _empty((max(1, 2 * int(off[-1])),), torch.float64)
+    T = _empty((ncam, 3), torch.float64)
+    hist = _empty((ncam, iters, 3), torch.float64) if want_history else None
+    C.check(lib.sfm_lm_translation_f64(C.dptr(K), C.dptr(pts), C.hptr(off), ncam, C.dptr(T0), int(iters), float(mu), C.dptr(work), C.dptr(T), C.dptr(hist), C.stream_ptr()))
+    return (T, hist) if want_history else T

@@ -1,0 +1,139 @@
+"""The library's small-matrix numerics (csrc/sfm_math.hpp) compiled for the host and checked
+against the oracle and the golden fixtures.  CPU only: finds solver bugs without a GPU; the
+GPU parity tests repeat these checks through the C-ABI."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import sfm_oracle as orc
+from sfm_hip import synthetic
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    src = os.path.join(HERE, "host_harness", "math_harness.cpp")
+    out = os.path.join(HERE, "host_harness", "libmath_harness.so")
+    hdr = os.path.join(ROOT, "structure-from-motion_amd", "csrc", "sfm_math.hpp")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-mfma", "-shared", "-fPIC",
+                               "-I" + os.path.dirname(hdr), "-o", out, src])
+    return ctypes.CDLL(out)
+
+
+def ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def pack_corr(x1, x2):
+    return np.ascontiguousarray(np.stack([x1[0], x1[1], x2[0], x2[1]], axis=1))
+
+
+def scene(n=1500, inl=0.5, pl=0.5, seed=11):
+    sc = synthetic.two_view_scene(n=n, inlier_ratio=inl, planar_ratio=pl, seed=seed)
+    return sc, orc.normalize_K(sc["K"], sc["x1"]), orc.normalize_K(sc["K"], sc["x2"])
+
+
+def up_to_sign(a, b):
+    a = a / np.linalg.norm(a)
+    b = b / np.linalg.norm(b)
+    return min(np.abs(a - b).max(), np.abs(a + b).max())
+
+
+def test_eh_models_and_counts_match_golden(lib, golden):
+    g = golden("eh_scoring.npz")
+    sc, x1, x2 = scene()
+    corr = pack_corr(x1, x2)
+    idx = g["idx"].astype(np.int32)
+    B = idx.shape[0]
+    E = np.zeros((B, 9)); H = np.zeros((B, 9))
+    lib.h_solve_eh(ptr(corr), ptr(idx), ctypes.c_int64(B), ptr(E), ptr(H))
+    for i in range(B):
+        assert up_to_sign(E[i].reshape(3, 3), g["E"][i]) < 1e-9
+        np.testing.assert_allclose(H[i].reshape(3, 3), g["H"][i], rtol=1e-7, atol=1e-9)
+    ce = np.zeros(B, np.int32); ch = np.zeros(B, np.int32)
+    thr = float(g["thr"])
+    lib.h_score_eh(ptr(corr), 1500, ptr(E), ptr(H), ctypes.c_int64(B), ctypes.c_double(thr), ctypes.c_double(3 * thr), ptr(ce), ptr(ch))
+    np.testing.assert_array_equal(ce, g["cE"])
+    np.testing.assert_array_equal(ch, g["cH"])
+
+
+def test_eh_counts_random_block_vs_oracle(lib):
+    sc, x1, x2 = scene(n=800, inl=0.6, pl=0.5, seed=3)
+    corr = pack_corr(x1, x2)
+    rng = np.random.default_rng(0)
+    B = 2000
+    idx = rng.integers(0, 800, size=(B, 12)).astype(np.int32)
+    thr = 1.0 / sc["K"][0][0]
+    cE, cH, Eo, Ho = orc.score_EH_batch(x1, x2, idx, thr)
+    E = np.zeros((B, 9)); H = np.zeros((B, 9))
+    lib.h_solve_eh(ptr(corr), ptr(idx), ctypes.c_int64(B), ptr(E), ptr(H))
+    ce = np.zeros(B, np.int32); ch = np.zeros(B, np.int32)
+    lib.h_score_eh(ptr(corr), 800, ptr(E), ptr(H), ctypes.c_int64(B), ctypes.c_double(thr), ctypes.c_double(3 * thr), ptr(ce), ptr(ch))
+    okE = np.array([len(set(r[:8])) == 8 for r in idx])
+    okH = np.array([len(set(r[8:])) == 4 for r in idx])
+    np.testing.assert_array_equal(ce[okE], cE[okE])
+    np.testing.assert_array_equal(ch[okH], cH[okH])
+
+
+def test_triangulation_matches_golden(lib, golden):
+    t = golden("triangulate.npz")
+    sc, x1, x2 = scene()
+    n = int(t["n"])
+    X = np.zeros((4, n))
+    a = np.ascontiguousarray(x1[:2, :n]); b = np.ascontiguousarray(x2[:2, :n])
+    lib.h_triangulate(ptr(np.ascontiguousarray(t["P1"])), ptr(np.ascontiguousarray(t["P2"])), ptr(a), ptr(b), n, n, ptr(X))
+    np.testing.assert_allclose(X, t["X"], rtol=1e-9, atol=1e-9)
+    Kn = np.asarray(sc["K"], float)
+    a = np.ascontiguousarray(sc["x1"][:2, :n]); b = np.ascontiguousarray(sc["x2"][:2, :n])
+    lib.h_triangulate(ptr(np.ascontiguousarray(Kn @ t["P1"])), ptr(np.ascontiguousarray(Kn @ t["P2"])), ptr(a), ptr(b), n, n, ptr(X))
+    np.testing.assert_allclose(X, t["Xpix"], rtol=1e-7, atol=1e-7)
+
+
+def test_decompositions_match_golden(lib, golden):
+    g = golden("eh_scoring.npz")
+    d = golden("decomp.npz")
+    sc, x1, x2 = scene()
+    for k, i in enumerate(d["sel"]):
+        P = np.zeros((4, 12))
+        lib.h_essential_candidates(ptr(np.ascontiguousarray(g["E"][i])), ptr(P))
+        cands = [p.reshape(3, 4) for p in P]
+        # the reference's pick must be among the four candidates
+        ref = np.hstack([d["R_e"][k], d["T_e"][k].reshape(3, 1)])
+        assert min(np.abs(c - ref).max() for c in cands) < 1e-9
+        for c in cands:
+            assert abs(np.linalg.det(c[:, :3]) - 1) < 1e-9
+        # chirality pick over the candidates reproduces the reference's answer
+        bestP, n = orc.perform_chirality_check(cands, x1, x2)
+        assert n == d["n_e"][k]
+        np.testing.assert_allclose(bestP, ref, atol=1e-9)
+        Hm = d["H"][k]
+        pos = np.sum(np.sum(x2 * (Hm @ x1), axis=0) > 0)
+        out = np.zeros(42)
+        lib.h_homography_decompose(ptr(np.ascontiguousarray(Hm)), int(pos < x1.shape[1] / 2), ptr(out))
+        R1, t1, R2, t2 = out[:9].reshape(3, 3), out[9:12], out[12:21].reshape(3, 3), out[21:24]
+        sols = [(R1, t1), (R2, t2)]
+        for Rr, tr in ((d["R1"][k], d["t1"][k]), (d["R2"][k], d["t2"][k])):
+            assert min(max(np.abs(R - Rr).max(), np.abs(t - tr).max()) for R, t in sols) < 1e-8
+        np.testing.assert_allclose(out[24:33].reshape(3, 3), orc.skew_symmetric_mat(t1) @ R1, atol=1e-12)
+
+
+def test_t_two_point_matches_golden(lib, golden):
+    g = golden("t2pt.npz")
+    m, out, seed = g["scene"]
+    sc = synthetic.resection_scene(m=int(m), outlier_ratio=float(out), seed=int(seed))
+    RX = sc["R"] @ sc["X"].astype(np.float64)
+    pts = np.ascontiguousarray(np.concatenate([RX, sc["x_norm"]], axis=0).T)
+    idx = g["idx"].astype(np.int32)
+    B = idx.shape[0]
+    T = np.zeros((B, 3))
+    lib.h_solve_t2(ptr(pts), ptr(idx), ctypes.c_int64(B), ptr(T))
+    np.testing.assert_allclose(T, g["T"], rtol=1e-8, atol=1e-10)
+    cnt = np.zeros(B, np.int32)
+    lib.h_score_t(ptr(pts), int(m), ptr(T), ctypes.c_int64(B), ctypes.c_double(float(g["thr"])), ptr(cnt))
+    np.testing.assert_array_equal(cnt, g["counts"])
