@@ -95,6 +95,13 @@ int sfm_pack_points_f64(const double* R, const void* X, int32_t x_is_f64, const 
 int sfm_t_ransac_f64(const double* pts, const int64_t* cam_off, int32_t ncam, const int32_t* idx, int64_t nb, double thr,
                      int32_t* counts, uint64_t* best, double* T_best, void* stream);
 
+/* First maximum of an inlier-count array, folded into *best with max():
+ * key = (count << 32) | (0xFFFFFFFF - (index_base + i)), so that a larger count wins and, among
+ * equal counts, the lowest global hypothesis id: the strict `>` update of
+ * src/estimate_translation.py:73 and src/ransac_algorithm.py:105.  The caller zeroes *best
+ * (uint64[1]) before the first call; partial ranges and other GPUs' results combine by max. */
+int sfm_argmax_count_i32(const int32_t* counts, int64_t nb, uint64_t index_base, uint64_t* best, void* stream);
+
 /* Translations of given samples only: T_out double[nb][3] (estimate_T_2point, :80-106). */
 int sfm_t_models_f64(const double* pts, int32_t m, const int32_t* idx, int64_t nb, double* T_out, void* stream);
 

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 (rocpd sqlite) outputs of profiles/run_profile.sh into a text summary.
+
+    python profiles/summarize.py gpurun_out/prof_<tag> > profiles/<tag>_summary.txt
+"""
+import glob
+import os
+import sqlite3
+import sys
+
+
+def main(d):
+    tr = glob.glob(os.path.join(d, "trace", "*.db"))
+    if tr:
+        c = sqlite3.connect(tr[0])
+        print("== kernel trace (rocprofv3 --kernel-trace --stats): name | calls | total us | avg us | % ==")
+        for name, calls, tot, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+            print(f"{name[:110]:110s} | {calls:5d} | {tot:12.1f} | {avg:10.2f} | {pct:6.2f}")
+    for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
+        if not os.path.isdir(sub):
+            continue
+        dbs = glob.glob(os.path.join(sub, "*.db"))
+        if not dbs:
+            continue
+        c = sqlite3.connect(dbs[0])
+        print(f"\n== {os.path.basename(sub)} (rocprofv3 --pmc): per-kernel average over dispatches of the per-dispatch counter sum ==")
+        rows = c.execute(
+            "select name, counter_name, avg(v), count(*), avg(dur) from (select name, counter_name, dispatch_id, sum(counter_value) v, "
+            "max(duration) dur from pmc_events group by name, counter_name, dispatch_id) group by name, counter_name"
+        ).fetchall()
+        for name, cn, v, n, dur in rows:
+            if "eh_score" in name or "t_score" in name or "argmax" in name or "lm_kernel" in name:
+                print(f"{name[:70]:70s} | {cn:22s} | {v:18.1f} | dispatches {n} | avg dur {dur/1e3:10.1f} us")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -298,11 +298,13 @@ __global__ __launch_bounds__(kBlock) void t_models_kernel(const double* __restri
 }
 
 // first maximum of counts[cam][0..nb): key = (count << 32) | (0xFFFFFFFF - index), max over keys
-__global__ __launch_bounds__(kBlock) void argmax_kernel(const int* __restrict__ counts, long long nb, unsigned long long* __restrict__ best) {
+__global__ __launch_bounds__(kBlock) void argmax_kernel(const int* __restrict__ counts, long long nb, unsigned long long index_base,
+                                                        unsigned long long* __restrict__ best) {
   const int cam = blockIdx.y;
   unsigned long long key = 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += (long long)gridDim.x * blockDim.x) {
-    const unsigned long long k = ((unsigned long long)(unsigned)counts[(long long)cam * nb + i] << 32) | (0xFFFFFFFFull - (unsigned long long)i);
+    const unsigned long long k =
+        ((unsigned long long)(unsigned)counts[(long long)cam * nb + i] << 32) | (0xFFFFFFFFull - (index_base + (unsigned long long)i));
     key = k > key ? k : key;
   }
 #pragma unroll
@@ -639,10 +641,20 @@ int sfm_t_ransac_f64(const double* pts, const int64_t* cam_off, int32_t ncam, co
   rc = check_launch();
   if (rc) return rc;
   const int ablocks = (int)(tiles < 256 ? tiles : 256);
-  argmax_kernel<<<dim3(ablocks, ncam), kBlock, 0, st>>>(counts, nb, (unsigned long long*)best);
+  argmax_kernel<<<dim3(ablocks, ncam), kBlock, 0, st>>>(counts, nb, 0ull, (unsigned long long*)best);
   rc = check_launch();
   if (rc) return rc;
   t_winner_kernel<<<ncam, 64, 0, st>>>(pts, offs, idx, nb, (const unsigned long long*)best, T_best);
+  return check_launch();
+}
+
+int sfm_argmax_count_i32(const int32_t* counts, int64_t nb, uint64_t index_base, uint64_t* best, void* stream) {
+  clear_stale_error();
+  if (!counts || !best || nb < 0 || index_base + (uint64_t)nb > 0xFFFFFFFFull) return SFM_EINVAL;
+  if (nb == 0) return 0;
+  const long long tiles = (nb + kBlock - 1) / kBlock;
+  const int ablocks = (int)(tiles < 1024 ? tiles : 1024);
+  argmax_kernel<<<dim3(ablocks, 1), kBlock, 0, (hipStream_t)stream>>>(counts, nb, index_base, (unsigned long long*)best);
   return check_launch();
 }
 

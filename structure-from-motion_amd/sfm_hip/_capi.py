@@ -29,6 +29,7 @@ _SIGS = {
     "sfm_triangulate_f64": (_c.c_int, [_P, _P, _P, _P, _c.c_int32, _c.c_int64, _P, _P]),
     "sfm_pack_points_f64": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int32, _P, _P]),
     "sfm_t_ransac_f64": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _P, _P, _P, _P]),
+    "sfm_argmax_count_i32": (_c.c_int, [_P, _c.c_int64, _c.c_uint64, _P, _P]),
     "sfm_t_models_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _P, _P]),
     "sfm_lm_translation_f64": (_c.c_int, [_P, _P, _P, _c.c_int32, _P, _c.c_int32, _c.c_double, _P, _P, _P, _P]),
 }

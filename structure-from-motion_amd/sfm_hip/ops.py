@@ -148,6 +148,16 @@ def t_ransac(pts, cam_sizes, idx, thr):
     return best, T, counts
 
 
+def argmax_count(counts, index_base=0, best=None):
+    """counts int32 [B] -> best int64 [1] holding the packed (count, lowest index) key."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    if best is None:
+        best = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    C.check(lib.sfm_argmax_count_i32(C.dptr(counts), counts.shape[0], int(index_base), C.dptr(best), C.stream_ptr()))
+    return best
+
+
 def decode_best(best_host):
     """uint64 keys (as int64) -> (count, index) arrays."""
     k = np.asarray(best_host).astype(np.uint64)
