@@ -56,6 +56,14 @@ int sfm_epipolar_mask_f64(const double* E, const double* corr, int32_t n, double
 int sfm_transfer_mask_f64(const double* H, const double* corr, int32_t n, double thr, uint8_t* mask, int32_t* count,
                           void* stream);
 
+/* Point-to-epipolar-line distances d[n] of one matrix, src/ransac_algorithm.py:193-213.
+ * x1, x2: the 3xN homogeneous point arrays, row stride ld doubles. */
+int sfm_epipolar_errors_f64(const double* F, const double* x1, const double* x2, int32_t n, int64_t ld, double* d,
+                            void* stream);
+
+/* U diag(1,1,0) V^T of one 3x3 matrix, src/ransac_algorithm.py:176-190. */
+int sfm_enforce_essential_f64(const double* F, double* E, void* stream);
+
 /* Four motion candidates of an essential matrix, P2s double[4][12]:
  * src/ransac_algorithm.py:422-435 (SVD, determinant sign fix, [UWVt|+-u3], [UW'Vt|+-u3]). */
 int sfm_essential_candidates_f64(const double* E, double* P2s, void* stream);
@@ -94,6 +102,10 @@ int sfm_pack_points_f64(const double* R, const void* X, int32_t x_is_f64, const 
  * the count is 0: the reference returns None then). */
 int sfm_t_ransac_f64(const double* pts, const int64_t* cam_off, int32_t ncam, const int32_t* idx, int64_t nb, double thr,
                      int32_t* counts, uint64_t* best, double* T_best, void* stream);
+
+/* Inlier counts of nb given translations T double[nb][3] over one camera's packed points:
+ * count_inliers, src/estimate_translation.py:109-129.  counts: int32[nb]. */
+int sfm_t_count_f64(const double* pts, int32_t m, const double* T, int64_t nb, double thr, int32_t* counts, void* stream);
 
 /* First maximum of an inlier-count array, folded into *best with max():
  * key = (count << 32) | (0xFFFFFFFF - (index_base + i)), so that a larger count wins and, among

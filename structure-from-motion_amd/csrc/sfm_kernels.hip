@@ -129,6 +129,35 @@ __global__ __launch_bounds__(kBlock) void mask_kernel(const double* __restrict__
   if (count && threadIdx.x == 0 && c) atomicAdd(count, c);
 }
 
+// |l . x2| / sqrt(l0^2 + l1^2) with l = F x1, for callers that want the distances themselves
+// (src/ransac_algorithm.py:193-213).  x1, x2 are the 3xN arrays (row stride ld).
+__global__ __launch_bounds__(kBlock) void epipolar_errors_kernel(const double* __restrict__ F, const double* __restrict__ x1,
+                                                                 const double* __restrict__ x2, int n, long long ld, double* __restrict__ d) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const double a = x1[j], b = x1[ld + j], c = x1[2 * ld + j];
+  double l[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) l[i] = (F[3 * i] * a + F[3 * i + 1] * b) + F[3 * i + 2] * c;
+  const double nrm = sqrt(l[0] * l[0] + l[1] * l[1]);
+  d[j] = fabs(((l[0] / nrm) * x2[j] + (l[1] / nrm) * x2[ld + j]) + (l[2] / nrm) * x2[2 * ld + j]);
+}
+
+__global__ void enforce_essential_kernel(const double* __restrict__ F, double* __restrict__ E) {
+  double A[3][3], U[3][3], S[3], V[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) A[i][j] = F[3 * i + j];
+  svd3<double>(A, U, S, V);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) E[3 * i + j] = fma(U[i][0], V[j][0], U[i][1] * V[j][1]);
+  }
+}
+
 __global__ void essential_candidates_kernel(const double* __restrict__ E, double* __restrict__ P2s) {
   double e[9], P[4][12];
 #pragma unroll
@@ -295,6 +324,21 @@ __global__ __launch_bounds__(kBlock) void t_models_kernel(const double* __restri
   solve_T2<double>(x, r, idx[2 * gid] == idx[2 * gid + 1], T);
 #pragma unroll
   for (int i = 0; i < 3; ++i) T_out[3 * gid + i] = T[i];
+}
+
+// inlier counts of given translations over one camera's points (one translation per lane)
+__global__ __launch_bounds__(kBlock) void t_count_kernel(const double* __restrict__ pts, int m, const double* __restrict__ Ts, long long nb,
+                                                         double thr2, int* __restrict__ counts) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long h = gid < nb ? gid : nb - 1;
+  const double T0 = Ts[3 * h], T1 = Ts[3 * h + 1], T2 = Ts[3 * h + 2];
+  int c = 0;
+#pragma unroll 4
+  for (int j = 0; j < m; ++j) {
+    const double* p = pts + 6LL * j;
+    c += reprojection_inlier<double>(T0, T1, T2, p[0], p[1], p[2], p[3], p[4], thr2) ? 1 : 0;
+  }
+  if (gid < nb) counts[gid] = c;
 }
 
 // first maximum of counts[cam][0..nb): key = (count << 32) | (0xFFFFFFFF - index), max over keys
@@ -557,6 +601,21 @@ int sfm_transfer_mask_f64(const double* H, const double* corr, int32_t n, double
   return mask_common(false, H, corr, n, thr, mask, count, stream);
 }
 
+int sfm_epipolar_errors_f64(const double* F, const double* x1, const double* x2, int32_t n, int64_t ld, double* d, void* stream) {
+  clear_stale_error();
+  if (!F || !x1 || !x2 || !d || n < 0 || ld < n) return SFM_EINVAL;
+  if (n == 0) return 0;
+  epipolar_errors_kernel<<<div_up(n, kBlock), kBlock, 0, (hipStream_t)stream>>>(F, x1, x2, n, ld, d);
+  return check_launch();
+}
+
+int sfm_enforce_essential_f64(const double* F, double* E, void* stream) {
+  clear_stale_error();
+  if (!F || !E) return SFM_EINVAL;
+  enforce_essential_kernel<<<1, 64, 0, (hipStream_t)stream>>>(F, E);
+  return check_launch();
+}
+
 int sfm_essential_candidates_f64(const double* E, double* P2s, void* stream) {
   clear_stale_error();
   if (!E || !P2s) return SFM_EINVAL;
@@ -645,6 +704,14 @@ int sfm_t_ransac_f64(const double* pts, const int64_t* cam_off, int32_t ncam, co
   rc = check_launch();
   if (rc) return rc;
   t_winner_kernel<<<ncam, 64, 0, st>>>(pts, offs, idx, nb, (const unsigned long long*)best, T_best);
+  return check_launch();
+}
+
+int sfm_t_count_f64(const double* pts, int32_t m, const double* T, int64_t nb, double thr, int32_t* counts, void* stream) {
+  clear_stale_error();
+  if (!pts || !T || !counts || m < 0 || nb < 0) return SFM_EINVAL;
+  if (nb == 0) return 0;
+  t_count_kernel<<<div_up(nb, kBlock), kBlock, 0, (hipStream_t)stream>>>(pts, m, T, nb, thr * thr, counts);
   return check_launch();
 }
 

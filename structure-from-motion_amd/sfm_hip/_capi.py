@@ -23,12 +23,15 @@ _SIGS = {
     "sfm_eh_models_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _P, _P, _P, _P]),
     "sfm_epipolar_mask_f64": (_c.c_int, [_P, _P, _c.c_int32, _c.c_double, _P, _P, _P]),
     "sfm_transfer_mask_f64": (_c.c_int, [_P, _P, _c.c_int32, _c.c_double, _P, _P, _P]),
+    "sfm_epipolar_errors_f64": (_c.c_int, [_P, _P, _P, _c.c_int32, _c.c_int64, _P, _P]),
+    "sfm_enforce_essential_f64": (_c.c_int, [_P, _P, _P]),
     "sfm_essential_candidates_f64": (_c.c_int, [_P, _P, _P]),
     "sfm_chirality4_f64": (_c.c_int, [_P, _P, _P, _c.c_int32, _P, _P]),
     "sfm_homography_to_rt_f64": (_c.c_int, [_P, _P, _c.c_int32, _P, _P]),
     "sfm_triangulate_f64": (_c.c_int, [_P, _P, _P, _P, _c.c_int32, _c.c_int64, _P, _P]),
     "sfm_pack_points_f64": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int32, _P, _P]),
     "sfm_t_ransac_f64": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _P, _P, _P, _P]),
+    "sfm_t_count_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _c.c_double, _P, _P]),
     "sfm_argmax_count_i32": (_c.c_int, [_P, _c.c_int64, _c.c_uint64, _P, _P]),
     "sfm_t_models_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _P, _P]),
     "sfm_lm_translation_f64": (_c.c_int, [_P, _P, _P, _c.c_int32, _P, _c.c_int32, _c.c_double, _P, _P, _P, _P]),

@@ -1,0 +1,43 @@
+"""Chirality check with the reference's names (src/chirality_check.py), on the GPU."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _capi as C
+from . import ops
+
+
+def perform_chirality_check(P2s, x1, x2):
+    """Reference: src/chirality_check.py:5-36.  Triangulates every correspondence under each
+    of the four candidate second cameras (first camera [I|0]) and returns the candidate with
+    the most points in front of both cameras (first strict maximum) and that count."""
+    if len(P2s) != 4:
+        raise NotImplementedError("the GPU kernel scores exactly four candidates, as the reference pipeline does")
+    Pd = C.dev(np.stack([np.asarray(p, np.float64).reshape(12) for p in P2s]))
+    if np.asarray(x1).shape[1] == 0:
+        counts = np.zeros(4, np.int32)
+    else:
+        counts = ops.chirality4(Pd, C.dev(ops.pack_corr(x1, x2)), None).cpu().numpy()
+    best_idx, n = select_best_from_counts(counts)
+    return P2s[best_idx], n
+
+
+def select_best_from_counts(counts):
+    """The update rule of src/chirality_check.py:79-91 applied to precomputed counts."""
+    best, bi = -1, -1
+    for i, c in enumerate(counts):
+        if c > best:
+            best, bi = int(c), i
+    return bi, best
+
+
+def count_points_in_front_of_cam(P1, P2, points_3d):
+    """Reference: src/chirality_check.py:39-60, for already triangulated points (4xN).
+    A convenience for callers of the old API; the pipeline path counts inside the GPU kernel."""
+    with np.errstate(all="ignore"):
+        return int(np.sum(((P2 @ points_3d)[2] > 0) & ((P1 @ points_3d)[2] > 0)))
+
+
+def select_best_solution(triangulated_points, P1, P2s):
+    """Reference: src/chirality_check.py:63-91."""
+    return select_best_from_counts([count_points_in_front_of_cam(P1, P2s[i], X) for i, X in enumerate(triangulated_points)])

@@ -84,6 +84,24 @@ def transfer_mask(H, corr, thr):
     return mask, count
 
 
+def epipolar_errors(F, x1, x2):
+    """F float64 [9]; x1, x2 float64 [3][N] -> d float64 [N]."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    n = x1.shape[1]
+    d = _empty((n,), torch.float64)
+    C.check(lib.sfm_epipolar_errors_f64(C.dptr(F), C.dptr(x1), C.dptr(x2), n, x1.stride(0), C.dptr(d), C.stream_ptr()))
+    return d
+
+
+def enforce_essential(F):
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    E = _empty((9,), torch.float64)
+    C.check(lib.sfm_enforce_essential_f64(C.dptr(F), C.dptr(E), C.stream_ptr()))
+    return E
+
+
 def essential_candidates(E):
     torch = C.torch_cuda()
     lib = C.load_library()
@@ -146,6 +164,16 @@ def t_ransac(pts, cam_sizes, idx, thr):
     T = _empty((ncam, 3), torch.float64)
     C.check(lib.sfm_t_ransac_f64(C.dptr(pts), C.hptr(off), ncam, C.dptr(idx), nb, float(thr), C.dptr(counts), C.dptr(best), C.dptr(T), C.stream_ptr()))
     return best, T, counts
+
+
+def t_count(pts, T, thr):
+    """pts float64 [M][6]; T float64 [B][3] -> counts int32 [B]."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    nb = T.shape[0]
+    counts = _empty((nb,), torch.int32)
+    C.check(lib.sfm_t_count_f64(C.dptr(pts), pts.shape[0], C.dptr(T), nb, float(thr), C.dptr(counts), C.stream_ptr()))
+    return counts
 
 
 def argmax_count(counts, index_base=0, best=None):

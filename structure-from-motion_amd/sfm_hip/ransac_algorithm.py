@@ -1,0 +1,297 @@
+"""Two-view E/H RANSAC with the names and signatures of the reference's
+src/ransac_algorithm.py, running on the GPU.
+
+estimate_E_robust reproduces the reference's sequential state machine (adaptive trip count,
+E and H record events, the H branch that may overwrite and even lower the best E count) by
+replaying it over inlier counts that the GPU computes for blocks of pre-drawn index sets.
+The index sets come from the global legacy np.random stream in the reference's order (8 then
+4 integers per iteration); on return the stream is exactly where the reference leaves it.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import time
+
+import numpy as np
+
+from . import _capi as C
+from . import ops
+from .utils import normalize_K
+
+try:  # progress bars are a side effect of the reference too (src/ransac_algorithm.py:25)
+    from tqdm import tqdm
+except Exception:  # pragma: no cover
+
+    def tqdm(it, **kw):
+        return it
+
+
+ALPHA = 0.95  # src/ransac_algorithm.py:77
+EPS0 = 0.1  # :78-79
+S_E, S_H = 8, 4  # :75-76
+
+
+def ransac_iters(eps, s):
+    """|log(1-alpha)/log(1-eps^s)| of src/ransac_algorithm.py:87-88, :112, :156-157; like the
+    reference it is inf when 1-eps^s rounds to 1."""
+    with np.errstate(all="ignore"):
+        return np.abs(np.log(1 - ALPHA) / np.log(1 - np.float64(eps) ** s))
+
+
+class ReplayState:
+    """The reference's loop state (src/ransac_algorithm.py:74-90)."""
+
+    def __init__(self, n):
+        self.n = n
+        self.best_E = 0
+        self.best_H = 0
+        self.E_iters = ransac_iters(EPS0, S_E)
+        self.H_iters = ransac_iters(EPS0, S_H)
+        self.it = 0
+        self.R = None
+        self.T = None
+        self.inliers = None
+        self.events = []  # (iteration, 'E'|'H', accepted) for logging and tests
+
+    def limit(self):
+        return max(self.E_iters, self.H_iters)
+
+
+def replay_block(st, idx, cE, cH, backend):
+    """Advances the state machine over one block of hypotheses.
+
+    idx: (nb,12) index sets, cE/cH: their inlier counts.  Returns the number of iterations of
+    the block the reference would have executed (== nb unless the loop ended inside it)."""
+    nb = idx.shape[0]
+    j = 0
+    while j < nb:
+        lim = st.limit()
+        remaining = lim - st.it
+        if np.isfinite(lim):
+            k_stop = j + (int(math.ceil(remaining)) if remaining > 0 else 0)
+        else:
+            k_stop = nb + 1
+        ev = np.flatnonzero((cE[j:] > st.best_E) | (cH[j:] > st.best_H))
+        k_event = j + int(ev[0]) if ev.size else nb
+        k_next = min(k_event, k_stop, nb)
+        st.it += k_next - j
+        j = k_next
+        if j >= nb:
+            break
+        if k_stop <= k_event:
+            return j  # `while iterations < max(E_iters, H_iters)` is false here (:91)
+        nE = int(cE[j])
+        if nE > st.best_E:  # :105-113
+            st.best_E = nE
+            st.R, st.T, st.inliers = backend.e_record(idx[j])
+            st.E_iters = ransac_iters(st.best_E / st.n, S_E)
+            st.events.append((st.it, "E", True))
+        nH = int(cH[j])
+        if nH > st.best_H:  # :124-169
+            st.best_H = nH
+            (Ra, Ta, na, ma), (Rb, Tb, nb_, mb) = backend.h_record(idx[j])
+            pick = None
+            if na > nb_:
+                if na > nE:
+                    pick = (Ra, Ta, na, ma)
+            else:
+                if nb_ > nE:
+                    pick = (Rb, Tb, nb_, mb)
+            if pick is not None:
+                st.R, st.T, st.best_E, st.inliers = pick
+                st.H_iters = ransac_iters(st.best_H / st.n, S_H)
+                st.E_iters = ransac_iters(st.best_E / st.n, S_E)
+            st.events.append((st.it, "H", pick is not None))
+        st.it += 1
+        j += 1
+    return j
+
+
+def run_replay(n, backend, chunk0=4096, chunk_max=1 << 18, max_iterations=None):
+    """Draws index blocks from np.random, scores them through `backend` and replays the state
+    machine; rewinds the stream so that exactly 12 integers per executed iteration are consumed."""
+    st = ReplayState(n)
+    chunk = chunk0
+    while st.it < st.limit():
+        if max_iterations is not None and st.it >= max_iterations:
+            break
+        lim = st.limit()
+        nb = chunk if not np.isfinite(lim) else int(min(chunk, max(1, math.ceil(lim - st.it))))
+        if max_iterations is not None:
+            nb = max(1, min(nb, max_iterations - st.it))
+        rng_state = np.random.get_state()
+        idx = np.random.randint(0, n, size=12 * nb).reshape(nb, 12)
+        cE, cH = backend.score(idx)
+        used = replay_block(st, idx, cE, cH, backend)
+        if used < nb:
+            np.random.set_state(rng_state)
+            if used > 0:
+                np.random.randint(0, n, size=12 * used)
+            break
+        chunk = min(chunk * 2, chunk_max)
+    return st
+
+
+def first_strict_max(counts):
+    """select_best_solution of src/chirality_check.py:79-91: start at -1, strict '>'."""
+    best, bi = -1, -1
+    for i, c in enumerate(counts):
+        if c > best:
+            best, bi = int(c), i
+    return bi, best
+
+
+class GpuBackend:
+    """Device side of the replay: block scoring and the two kinds of record event."""
+
+    def __init__(self, x1, x2, err_threshold):
+        self.thr = float(err_threshold)
+        self.corr = C.dev(ops.pack_corr(x1, x2))
+        self.n = self.corr.shape[0]
+
+    def score(self, idx):
+        d_idx = C.dev(idx, np.int32)
+        ce, ch = ops.eh_score(self.corr, d_idx, self.thr, 3 * self.thr)
+        return ce.cpu().numpy(), ch.cpu().numpy()
+
+    def _models(self, row):
+        return ops.eh_models(self.corr, C.dev(np.asarray(row)[None, :], np.int32))
+
+    def _decompose(self, E, mask):
+        P = ops.essential_candidates(E)
+        counts = ops.chirality4(P, self.corr, mask)
+        return P, counts
+
+    def e_record(self, row):
+        """R, T of essential_to_RT over ALL points (src/ransac_algorithm.py:110) and the inlier mask."""
+        E, _ = self._models(row)
+        mask, _ = ops.epipolar_mask(E[0], self.corr, self.thr)
+        P, counts = self._decompose(E[0], None)
+        P = P.cpu().numpy()
+        bi, _ = first_strict_max(counts.cpu().numpy())
+        Pb = P[bi].reshape(3, 4)
+        return Pb[:, :3].copy(), Pb[:, 3].copy(), mask
+
+    def h_record(self, row):
+        """Both homography solutions scored as src/ransac_algorithm.py:128-147."""
+        _, H = self._models(row)
+        rt = ops.homography_to_rt(H[0], self.corr)
+        out = []
+        staged = []
+        for off in (24, 33):
+            E = rt[off : off + 9]
+            mask, _ = ops.epipolar_mask(E, self.corr, self.thr)
+            P, counts = self._decompose(E, mask)
+            staged.append((P, counts, mask))
+        for P, counts, mask in staged:
+            bi, n = first_strict_max(counts.cpu().numpy())
+            Pb = P.cpu().numpy()[bi].reshape(3, 4)
+            out.append((Pb[:, :3].copy(), Pb[:, 3].copy(), n, mask))
+        return out[0], out[1]
+
+
+def estimate_E_robust(K, x1, x2, pixel_threshold):
+    """Reference: src/ransac_algorithm.py:57-173.  x1, x2: K-normalised 3xN.
+    Returns (R (3,3), T (3,1), inliers bool (N,))."""
+    err_threshold = pixel_threshold / K[0][0]
+    backend = GpuBackend(x1, x2, err_threshold)
+    st = run_replay(x1.shape[1], backend)
+    if st.R is None:
+        # the reference fails the same way when no hypothesis ever has an inlier (:173)
+        raise UnboundLocalError("local variable 'R_best' referenced before assignment")
+    inliers = st.inliers.cpu().numpy().astype(bool)
+    logging.debug("E/H RANSAC: %d iterations, events %s", st.it, st.events)
+    return st.R, np.reshape(st.T, (3, 1)), inliers
+
+
+def run_ransac(K, x1, x2, pixel_threshold):
+    """Reference: src/ransac_algorithm.py:47-54."""
+    return estimate_E_robust(K, normalize_K(K, x1), normalize_K(K, x2), pixel_threshold)
+
+
+def estimate_R(K, x_pairs, pixel_threshold):
+    """Reference: src/ransac_algorithm.py:10-44: relative rotation of each consecutive pair."""
+    R_list = []
+    for i in tqdm(range(len(x_pairs) // 2), desc="Running RANSAC"):
+        t0 = time.time()
+        logging.info(f"Processing pair {i+1}/{len(x_pairs) // 2}")
+        R, _, inliers = run_ransac(K, x_pairs[2 * i], x_pairs[2 * i + 1], pixel_threshold)
+        logging.info(f"RANSAC completed for pair {i+1} in {time.time() - t0:.2f} seconds with {len(inliers)} inliers")
+        R_list.append(R)
+    return R_list
+
+
+# ---- single-model functions of the reference module, each one GPU call --------------------
+
+
+def _sample_corr(x1s, x2s, need):
+    x1s = np.asarray(x1s, np.float64)
+    x2s = np.asarray(x2s, np.float64)
+    if x1s.shape[1] != need:
+        raise NotImplementedError(f"the in-register solver takes exactly {need} correspondences, got {x1s.shape[1]}")
+    return ops.pack_corr(x1s, x2s)
+
+
+def estimate_F_DLT(x1s, x2s):
+    """Reference: src/ransac_algorithm.py:216-263 for the minimal 8-point case (sign of F is
+    arbitrary there as well: it is a singular vector)."""
+    corr = _sample_corr(x1s, x2s, 8)
+    idx = np.concatenate([np.arange(8), np.arange(4)])[None, :]
+    F, _, _ = ops.eh_models(C.dev(corr), C.dev(idx, np.int32), want_F=True)
+    return F.cpu().numpy().reshape(3, 3)
+
+
+def enforce_essential(E):
+    """Reference: src/ransac_algorithm.py:176-190."""
+    return ops.enforce_essential(C.dev(np.asarray(E, np.float64).reshape(9))).cpu().numpy().reshape(3, 3)
+
+
+def estimate_H_DLT(x1s, x2s):
+    """Reference: src/ransac_algorithm.py:266-293 (four correspondences)."""
+    corr = _sample_corr(x1s, x2s, 4)
+    corr8 = np.concatenate([corr, corr], axis=0)
+    idx = np.concatenate([np.arange(8), np.arange(4)])[None, :]
+    _, H = ops.eh_models(C.dev(corr8), C.dev(idx, np.int32))
+    return H.cpu().numpy().reshape(3, 3)
+
+
+def epipolar_errors(F, x1, x2):
+    """Reference: src/ransac_algorithm.py:193-213."""
+    d = ops.epipolar_errors(C.dev(np.asarray(F, np.float64).reshape(9)), C.dev(x1, np.float64), C.dev(x2, np.float64))
+    return d.cpu().numpy()
+
+
+def get_inlier_mask_H(H, x1s, x2s, threshold):
+    """Reference: src/ransac_algorithm.py:296-329."""
+    corr = C.dev(ops.pack_corr(x1s, x2s))
+    mask, _ = ops.transfer_mask(C.dev(np.asarray(H, np.float64).reshape(9)), corr, threshold)
+    return mask.cpu().numpy().astype(bool)
+
+
+def homography_to_RT(H, x1, x2):
+    """Reference: src/ransac_algorithm.py:332-403.  Like the reference, H is negated IN PLACE
+    when fewer than half of the points have x2 . (H x1) > 0 (:359-361)."""
+    corr = C.dev(ops.pack_corr(x1, x2))
+    Hd = C.dev(np.asarray(H, np.float64).reshape(9))
+    out = ops.homography_to_rt(Hd, corr).cpu().numpy()
+    x1h = np.asarray(x1, np.float64)
+    x2h = np.asarray(x2, np.float64)
+    if isinstance(H, np.ndarray):
+        positives = np.sum(np.sum(x2h * (H @ x1h), axis=0) > 0)
+        if positives < x1h.shape[1] / 2:
+            H *= -1
+    return out[:9].reshape(3, 3), out[9:12].copy(), out[12:21].reshape(3, 3), out[21:24].copy()
+
+
+def essential_to_RT(E, x1, x2):
+    """Reference: src/ransac_algorithm.py:406-446."""
+    corr = C.dev(ops.pack_corr(x1, x2)) if np.asarray(x1).shape[1] else None
+    P = ops.essential_candidates(C.dev(np.asarray(E, np.float64).reshape(9)))
+    if corr is None:
+        counts = np.zeros(4, np.int32)
+    else:
+        counts = ops.chirality4(P, corr, None).cpu().numpy()
+    bi, n = first_strict_max(counts)
+    Pb = P.cpu().numpy()[bi].reshape(3, 4)
+    return Pb[:, :3].copy(), Pb[:, 3].copy(), n

@@ -1,0 +1,79 @@
+"""Host logic of the E/H RANSAC replay (sfm_hip.ransac_algorithm.run_replay) with a backend
+built from the oracle: the block-wise replay must reproduce the reference's sequential loop
+(fixtures) for any block size, and leave np.random where the reference leaves it.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import sfm_oracle as orc
+from sfm_hip import synthetic
+from sfm_hip.ransac_algorithm import first_strict_max, ransac_iters, run_replay
+
+
+class OracleBackend:
+    def __init__(self, x1, x2, thr):
+        self.x1, self.x2, self.thr = x1, x2, thr
+        self.blocks = []
+
+    def score(self, idx):
+        self.blocks.append(idx.shape[0])
+        cE, cH, _, _ = orc.score_EH_batch(self.x1, self.x2, idx, self.thr)
+        return cE, cH
+
+    def e_record(self, row):
+        E = orc.enforce_essential(orc.estimate_F_DLT(self.x1[:, row[:8]], self.x2[:, row[:8]]))
+        R, T, _ = orc.essential_to_RT(E, self.x1, self.x2)
+        return R, T, orc.epipolar_mask(E, self.x1, self.x2, self.thr)
+
+    def h_record(self, row):
+        H = orc.estimate_H_DLT(self.x1[:, row[8:]], self.x2[:, row[8:]])
+        Ra, Ta, Rb, Tb = orc.homography_to_RT(H, self.x1, self.x2)
+        out = []
+        for R, T in ((Ra, Ta), (Rb, Tb)):
+            E = orc.skew_symmetric_mat(T) @ R
+            m = orc.epipolar_mask(E, self.x1, self.x2, self.thr)
+            Rr, Tr, n = orc.essential_to_RT(E, self.x1[:, m], self.x2[:, m])
+            out.append((Rr, Tr, n, m))
+        return out[0], out[1]
+
+
+@pytest.mark.parametrize("tag,chunk0", [("a", 4096), ("a", 7), ("b", 64), ("c", 1), ("c", 1000)])
+def test_replay_reproduces_reference_runs(golden, tag, chunk0):
+    g = golden("eh_ransac.npz")
+    n, inl, pl, seed = g[f"{tag}_scene"]
+    sc = synthetic.two_view_scene(n=int(n), inlier_ratio=float(inl), planar_ratio=float(pl), seed=int(seed))
+    x1 = orc.normalize_K(sc["K"], sc["x1"])
+    x2 = orc.normalize_K(sc["K"], sc["x2"])
+    np.random.seed(int(g[f"{tag}_seed"]))
+    be = OracleBackend(x1, x2, 1.0 / sc["K"][0][0])
+    st = run_replay(int(n), be, chunk0=chunk0)
+    assert st.it == len(g[f"{tag}_cH"])
+    np.testing.assert_allclose(st.R, g[f"{tag}_R"], atol=1e-9)
+    np.testing.assert_allclose(np.reshape(st.T, (3, 1)), g[f"{tag}_T"], atol=1e-9)
+    np.testing.assert_array_equal(np.packbits(st.inliers), g[f"{tag}_inliers"])
+    np.testing.assert_array_equal(np.random.randint(0, 2**31 - 1, size=4), g[f"{tag}_next_draws"])
+    assert any(k == "E" for _, k, _ in st.events) and any(k == "H" for _, k, _ in st.events)
+
+
+def test_iteration_formula_edge_cases():
+    assert np.isinf(ransac_iters(1e-3, 8))  # 1 - eps^8 rounds to 1: the reference divides by log(1) = 0
+    assert abs(ransac_iters(0.1, 4) - 29955.8) < 1.0
+    assert ransac_iters(1.0, 8) == 0.0  # log(0) = -inf
+    assert first_strict_max([0, 0, 0, 0]) == (0, 0)
+    assert first_strict_max([3, 5, 5, 1]) == (1, 5)
+
+
+def test_replay_never_draws_past_a_finite_limit():
+    """Once both limits are finite the block size shrinks to what is left."""
+    sc = synthetic.two_view_scene(n=300, inlier_ratio=0.9, planar_ratio=0.8, seed=5)
+    x1 = orc.normalize_K(sc["K"], sc["x1"])
+    x2 = orc.normalize_K(sc["K"], sc["x2"])
+    np.random.seed(3)
+    ref = {}
+    orc.estimate_E_robust(sc["K"], x1, x2, 1.0, trace=ref)
+    after_ref = np.random.randint(0, 1000, 3)
+    np.random.seed(3)
+    be = OracleBackend(x1, x2, 1.0 / sc["K"][0][0])
+    st = run_replay(300, be, chunk0=16)
+    assert st.it == ref["iterations"]
+    np.testing.assert_array_equal(np.random.randint(0, 1000, 3), after_ref)
+    assert sum(be.blocks) >= st.it
