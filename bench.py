@@ -74,7 +74,7 @@ def main():
     import torch.distributed as dist
 
     from oracle import sfm_oracle as orc
-    from sfm_hip import _capi, ops, synthetic
+    from sfm_hip import _capi, ops, sharding, synthetic
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -108,8 +108,7 @@ def main():
         best.zero_()
         ops.argmax_count(ce, base, best[0:1])
         ops.argmax_count(ch, base, best[1:2])
-        if world > 1:
-            dist.all_reduce(best, op=dist.ReduceOp.MAX)
+        sharding.merge_best(best)  # RCCL all-reduce(max) of the packed winners when world > 1
 
     def sync():
         if world > 1:

@@ -1,0 +1,78 @@
+"""CPU checks: the shared library exports every symbol the header declares, the ctypes table
+matches the header, and the reference-named facade imports without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "sfm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sfm_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sfm_hip import _capi
+
+    lib = _capi.load_library()  # raises if the .so is missing: there is no fallback
+    names = header_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_capi.EXPORTED_SYMBOLS) == names
+    assert lib.sfm_hip_abi_version() == 1
+    assert b"invalid" in lib.sfm_hip_error_string(100001)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from sfm_hip import _capi
+
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", "/nonexistent/libsfm_hip.so")
+    with pytest.raises(_capi.SfmHipError):
+        _capi.load_library()
+
+
+def test_no_gpu_means_error_not_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy as np
+
+    import sfm_hip
+
+    x = np.vstack([np.random.default_rng(0).normal(size=(2, 20)), np.ones((1, 20))])
+    with pytest.raises(Exception) as e:
+        sfm_hip.run_ransac([[1000, 0, 0], [0, 1000, 0], [0, 0, 1]], x, x, 1.0)
+    assert "GPU" in str(e.value) or "fallback" in str(e.value)
+
+
+def test_facade_has_the_reference_names():
+    import src
+
+    for n in ["process_sift_for_image_pairs", "estimate_R", "run_reconstruction", "estimate_translation",
+              "refine_translation", "filter_3D_points", "triangulate_3D_point_DLT", "pflat", "homogeneous_to_cartesian"]:
+        assert callable(getattr(src, n))
+    import inspect
+
+    from sfm_hip import estimate_translation as et
+    from sfm_hip import ransac_algorithm as ra
+    from sfm_hip import refine_translation as rt
+
+    assert list(inspect.signature(ra.estimate_R).parameters) == ["K", "x_pairs", "pixel_threshold"]
+    assert list(inspect.signature(ra.estimate_E_robust).parameters) == ["K", "x1", "x2", "pixel_threshold"]
+    assert list(inspect.signature(et.robust_estimate_T).parameters) == ["x_norm", "X", "K", "R", "pixel_threshold"]
+    assert list(inspect.signature(rt.levenberg_marquardt_algorithm).parameters) == ["K", "R", "X", "x_norm", "T_initial", "num_iterations", "mu"]
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "structure-from-motion_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                assert "oracle" not in open(os.path.join(d, f)).read(), os.path.join(d, f)
