@@ -8,7 +8,9 @@
 // accumulated per lane (compare + add-with-carry), so no cross-lane reduction is needed.
 // Nothing is GEMM shaped; there is no MFMA in this library.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/sfm_hip.h"
 #include "sfm_math.hpp"
@@ -71,6 +73,115 @@ __global__ __launch_bounds__(kBlock) void eh_score_kernel(const double4* __restr
       count_e[gid] = ce;
       count_h[gid] = ch;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Float32 pre-filter: UPPER BOUNDS of the inlier counts.
+// The models are solved in float64 exactly as above, scaled to max-abs 1 (both tests are
+// homogeneous in the model, so the scale is free and float32 cannot overflow) and rounded to
+// float32; the matches are read from a float32 copy.  Each test is replaced by its
+// upper-bound form (sfm_math.hpp) whose slack constants are derived per hypothesis from a
+// first-order float32 error bound (input rounding of matches and model + the roundings of
+// the fma chains, doubled), so that every float64 inlier is also counted here: up >= exact.
+// Callers re-score the few hypotheses whose upper bound reaches the best exact count with
+// eh_score_kernel and so obtain the exact winner at about half the VALU cost per residual.
+// ---------------------------------------------------------------------------------------
+constexpr double kEps32 = 5.9604644775390625e-08;  // 2^-24
+
+__device__ __forceinline__ double to_unit_f32(const double (&M)[9], float (&Mf)[9], double (&Ma)[9]) {
+  double mx = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) mx = fmax(mx, fabs(M[i]));
+  const double inv = (mx > 0.0 && mx < 1.0e300) ? 1.0 / mx : 1.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    Mf[i] = (float)(M[i] * inv);
+    Ma[i] = fabs(M[i] * inv);
+  }
+  return inv;
+}
+
+__device__ __forceinline__ float round_up_f32(double v) {
+  const float f = (float)v;
+  return ((double)f < v) ? nextafterf(f, INFINITY) : f;
+}
+
+template <bool kAllowPacked>
+__global__ __launch_bounds__(kBlock) void eh_upper_kernel(const double4* __restrict__ corr, const float4* __restrict__ corr32, int n,
+                                                          const int32_t* __restrict__ idx, long long nb, double two_thr_e2, double thr_h2,
+                                                          double xmax, double safety, int* __restrict__ up_e, int* __restrict__ up_h,
+                                                          int points_per_split, int use_atomics) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long h = gid < nb ? gid : nb - 1;
+  float E[9], H[9];
+  float kp_e, c2_e, T_h, c1_h, c0_h;
+  {
+    double Ed[9], Hd[9], A[9];
+    double p8[8][4], p4[4][4];
+    gather_samples<double>(corr, idx + 12 * h, p8, p4);
+    solve_E8<double>(p8, Ed);
+    solve_H4<double>(p4, Hd);
+    to_unit_f32(Ed, E, A);
+    {
+      // row sums (for l = E x1) and column sums (for m = E^T x2) of |E| with |x|,|y| <= xmax
+      const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
+      const double C0 = xmax * (A[0] + A[3]) + A[6], C1 = xmax * (A[1] + A[4]) + A[7];
+      const double Es = 7.0 * kEps32 * (xmax * (R0 + R1) + R2);
+      const double eL = 6.0 * kEps32 * (R0 + R1 + C0 + C1);
+      const double rk = sqrt(two_thr_e2);
+      const double G = safety * (Es + rk * eL);
+      const double lam = rk;
+      kp_e = round_up_f32(two_thr_e2 * (1.0 + G / lam) * (1.0 + 16.0 * kEps32));
+      c2_e = round_up_f32((G * lam + G * G) * (1.0 + 16.0 * kEps32));
+    }
+    to_unit_f32(Hd, H, A);
+    {
+      const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
+      const double ez = 4.0 * kEps32 * R2;
+      const double Dx = 6.0 * kEps32 * (R0 + xmax * R2), Dy = 6.0 * kEps32 * (R1 + xmax * R2);
+      const double rt = sqrt(thr_h2);
+      const double G = safety * (rt * ez + Dx + Dy);
+      T_h = round_up_f32(thr_h2 * (1.0 + 16.0 * kEps32));
+      c1_h = round_up_f32(2.0 * rt * G * (1.0 + 16.0 * kEps32));
+      c0_h = round_up_f32(G * G * (1.0 + 16.0 * kEps32));
+    }
+  }
+  const int j0 = blockIdx.y * points_per_split;
+  const int j1 = min(n, j0 + points_per_split);
+  int ce = 0, ch = 0;
+  if constexpr (kAllowPacked) {
+#pragma unroll 8
+    for (int j = j0; j < j1; ++j) {
+      const float4 p = corr32[j];
+      ce += epipolar_upper_f32(E, p.x, p.y, p.z, p.w, kp_e, c2_e) ? 1 : 0;
+      ch += transfer_upper_f32(H, p.x, p.y, p.z, p.w, T_h, c1_h, c0_h) ? 1 : 0;
+    }
+  } else {
+#pragma clang loop vectorize(disable) interleave(disable)
+#pragma unroll 8
+    for (int j = j0; j < j1; ++j) {
+      const float4 p = corr32[j];
+      ce += epipolar_upper_f32(E, p.x, p.y, p.z, p.w, kp_e, c2_e) ? 1 : 0;
+      ch += transfer_upper_f32(H, p.x, p.y, p.z, p.w, T_h, c1_h, c0_h) ? 1 : 0;
+    }
+  }
+  if (gid < nb) {
+    if (use_atomics) {
+      atomicAdd(up_e + gid, ce);
+      atomicAdd(up_h + gid, ch);
+    } else {
+      up_e[gid] = ce;
+      up_h[gid] = ch;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void corr_to_f32_kernel(const double4* __restrict__ corr, int n, float4* __restrict__ corr32) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) {
+    const double4 c = corr[j];
+    corr32[j] = make_float4((float)c.x, (float)c.y, (float)c.z, (float)c.w);
   }
 }
 
@@ -563,6 +674,43 @@ int sfm_eh_score_f64(const double* corr, int32_t n, const int32_t* idx, int64_t 
   }
   eh_score_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, n, idx, nb, 2.0 * thr_e * thr_e, thr_h * thr_h,
                                                                     count_e, count_h, pps, splits > 1);
+  return check_launch();
+}
+
+int sfm_corr_to_f32(const double* corr, int32_t n, float* corr32, void* stream) {
+  clear_stale_error();
+  if (!corr || !corr32 || n < 0) return SFM_EINVAL;
+  if (n == 0) return 0;
+  corr_to_f32_kernel<<<div_up(n, kBlock), kBlock, 0, (hipStream_t)stream>>>((const double4*)corr, n, (float4*)corr32);
+  return check_launch();
+}
+
+int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
+                     double xmax, double safety, int32_t* up_e, int32_t* up_h, void* stream) {
+  clear_stale_error();
+  if (!corr || !corr32 || !idx || !up_e || !up_h || n <= 0 || nb < 0) return SFM_EINVAL;
+  if (!(xmax > 0.0 && xmax < 1.0e6 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
+  if (nb == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const long long tiles = (nb + kBlock - 1) / kBlock;
+  if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
+  const int splits = choose_splits(tiles, n);
+  const int pps = div_up(n, splits);
+  if (splits > 1) {
+    hipError_t e = hipMemsetAsync(up_e, 0, sizeof(int32_t) * nb, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(up_h, 0, sizeof(int32_t) * nb, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  static const bool unpacked = getenv("SFM_HIP_UPPER_UNPACKED") && atoi(getenv("SFM_HIP_UPPER_UNPACKED")) != 0;
+  if (!unpacked)
+    eh_upper_kernel<true><<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb,
+                                                                            2.0 * thr_e * thr_e, thr_h * thr_h, xmax, safety, up_e, up_h, pps,
+                                                                            splits > 1);
+  else
+    eh_upper_kernel<false><<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb,
+                                                                             2.0 * thr_e * thr_e, thr_h * thr_h, xmax, safety, up_e, up_h, pps,
+                                                                             splits > 1);
   return check_launch();
 }
 

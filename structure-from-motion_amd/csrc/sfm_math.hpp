@@ -306,6 +306,42 @@ SFM_FN bool transfer_inlier(const T (&H)[9], T x1, T y1, T x2, T y2, T thr2) {
   return d2 < thr2 * (hz * hz);
 }
 
+// ---------------------------------------------------------------------------------------
+// Float32 UPPER-BOUND forms of the two tests: true whenever the float64 test above is true
+// for the unrounded inputs, given absolute error bounds of the float32 evaluation.
+//
+// Epipolar: the exact test is |s| < sqrt(k) g(L1, L2) with L = sqrt(n), g = L1 L2 / sqrt(L1^2+L2^2)
+// (1-Lipschitz in L1 and in L2).  With |s - s_true| <= Es and |L - L_true| <= eL this implies
+// |s| < sqrt(k) g + G, G = Es + sqrt(k)(eL1 + eL2); multiplying by sqrt(n1+n2), squaring and
+// bounding the cross term by AM-GM with weight lambda gives
+//      (s^2 - c2)(n1 + n2) < k' n1 n2,   k' = k (1 + G/lambda),  c2 = G lambda + G^2.
+// Transfer: |d| < sqrt(T)|hz| with |d - d_true| <= D, |hz - hz_true| <= ez implies
+//      d^2 < T hz^2 + c1 |hz| + c0,  c1 = 2 sqrt(T) G, c0 = G^2, G = sqrt(T) ez + D.
+// The constants are per hypothesis (computed once from the model's row/column abs sums).
+// ---------------------------------------------------------------------------------------
+SFM_FN bool epipolar_upper_f32(const float (&E)[9], float x1, float y1, float x2, float y2, float kp, float c2) {
+  const float l0 = fma(E[0], x1, fma(E[1], y1, E[2]));
+  const float l1 = fma(E[3], x1, fma(E[4], y1, E[5]));
+  const float l2 = fma(E[6], x1, fma(E[7], y1, E[8]));
+  const float s = fma(l0, x2, fma(l1, y2, l2));
+  const float m0 = fma(E[0], x2, fma(E[3], y2, E[6]));
+  const float m1 = fma(E[1], x2, fma(E[4], y2, E[7]));
+  const float n1 = fma(l0, l0, l1 * l1);
+  const float n2 = fma(m0, m0, m1 * m1);
+  const float ss = fma(s, s, -c2);
+  return ss * (n1 + n2) < kp * (n1 * n2);
+}
+
+SFM_FN bool transfer_upper_f32(const float (&H)[9], float x1, float y1, float x2, float y2, float T, float c1, float c0) {
+  const float hx = fma(H[0], x1, fma(H[1], y1, H[2]));
+  const float hy = fma(H[3], x1, fma(H[4], y1, H[5]));
+  const float hz = fma(H[6], x1, fma(H[7], y1, H[8]));
+  const float dx = fma(x2, hz, -hx);
+  const float dy = fma(y2, hz, -hy);
+  const float d2 = fma(dx, dx, dy * dy);
+  return d2 < fma(T, hz * hz, fma(c1, fabs(hz), c0));
+}
+
 // Reprojection test of src/estimate_translation.py:123-127 with RX precomputed:
 // |pi(RX + T) - x| < thr  as  |(RX+T)_{xy} - x (RX+T)_z|^2 < thr^2 (RX+T)_z^2.
 template <typename T>

@@ -52,6 +52,68 @@ def eh_score(corr, idx, thr_e, thr_h, out=None):
     return ce, ch
 
 
+def corr_to_f32(corr):
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    out = _empty((corr.shape[0], 4), torch.float32)
+    C.check(lib.sfm_corr_to_f32(C.dptr(corr), corr.shape[0], C.dptr(out), C.stream_ptr()))
+    return out
+
+
+def eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, out=None):
+    """float32 pre-filter: upper bounds (up_e, up_h) int32 [B] of the exact counts.
+    xmax: max |coordinate| over corr (host float)."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    nb = idx.shape[0]
+    if out is None:
+        ue = _empty((nb,), torch.int32)
+        uh = _empty((nb,), torch.int32)
+    else:
+        ue, uh = out
+    C.check(lib.sfm_eh_upper_f32(C.dptr(corr), C.dptr(corr32), corr.shape[0], C.dptr(idx), nb, float(thr_e), float(thr_h),
+                                 float(xmax), float(safety), C.dptr(ue), C.dptr(uh), C.stream_ptr()))
+    return ue, uh
+
+
+def eh_best(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, scratch=None):
+    """Exact first-maximum winners of a block of hypotheses, two tiers:
+    float32 upper bounds for every hypothesis, float64 re-scoring of the candidates.
+
+    Returns ((count_e, index_e), (count_h, index_h), stats) with indices local to `idx`.
+    The result equals arg-max over sfm_eh_score_f64's counts with lowest-index tie-break."""
+    torch = C.torch_cuda()
+    nb = idx.shape[0]
+    ue, uh = eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety, out=scratch)
+    keys = torch.zeros((2,), dtype=torch.int64, device="cuda")
+    argmax_count(ue, 0, keys[0:1])
+    argmax_count(uh, 0, keys[1:2])
+    lead = 0xFFFFFFFF - (keys & 0xFFFFFFFF)  # ids of the largest upper bounds, still on the device
+    ce, ch = eh_score(corr, idx.index_select(0, lead), thr_e, thr_h)
+    floor = torch.stack([ce[0], ch[1]]).to(torch.int64)  # exact counts of the two leaders
+    mask_e = ue >= floor[0]
+    mask_h = uh >= floor[1]
+    # one host round trip: leaders, their exact counts and the number of candidates
+    info = torch.cat([lead, floor, torch.stack([mask_e.sum(), mask_h.sum()])]).cpu().numpy()
+    le, lh, fe, fh, ne, nh = (int(v) for v in info)
+    win_e, win_h = (fe, le), (fh, lh)
+    if ne > 1 or nh > 1:
+        # several hypotheses could still beat (or tie with a lower id than) a leader: re-score them exactly
+        cand_e = torch.nonzero(mask_e).flatten() if ne > 1 else lead[0:1]
+        cand_h = torch.nonzero(mask_h).flatten() if nh > 1 else lead[1:2]
+        cand = torch.cat([cand_e, cand_h])
+        ce, ch = eh_score(corr, idx.index_select(0, cand), thr_e, thr_h)
+        k = cand_e.shape[0]
+        res = torch.cat([cand, ce.to(torch.int64), ch.to(torch.int64)]).cpu().numpy()
+        m = cand.shape[0]
+        ids, xe, xh = res[:m], res[m : 2 * m], res[2 * m :]
+        ie = int(np.argmax(xe[:k]))  # ascending ids: the first maximum is the lowest id
+        ih = int(np.argmax(xh[k:]))
+        win_e = (int(xe[ie]), int(ids[ie]))
+        win_h = (int(xh[k + ih]), int(ids[k + ih]))
+    return win_e, win_h, {"candidates_e": ne, "candidates_h": nh}
+
+
 def eh_models(corr, idx, want_F=False):
     torch = C.torch_cuda()
     lib = C.load_library()

@@ -185,3 +185,44 @@ def test_lm_golden_batched(ops, dev, golden):
             assert np.abs(hist.cpu().numpy()[j] - ref).max() < 1e-4 * rms
             np.testing.assert_allclose(hist.cpu().numpy()[j], ref, rtol=1e-9, atol=1e-12)
             np.testing.assert_allclose(T.cpu().numpy()[j], ref[-1], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,B,seed", [(2000, 20000, 1), (500, 4000, 2), (10000, 3000, 3)])
+def test_f32_upper_bounds_and_two_tier_winner(ops, dev, n, B, seed):
+    """The float32 pre-filter never undercounts, and eh_best returns the exact first maximum."""
+    sc, x1, x2 = scene(n=n, inl=0.4, pl=0.5, seed=seed)
+    corr_h = ops.pack_corr(x1, x2)
+    corr = dev(corr_h)
+    c32 = ops.corr_to_f32(corr)
+    xmax = float(np.abs(corr_h).max())
+    rng = np.random.default_rng(seed)
+    idx_h = rng.integers(0, n, size=(B, 12)).astype(np.int32)
+    idx = dev(idx_h)
+    thr = 1.0 / sc["K"][0][0]
+    ce, ch = [t.cpu().numpy() for t in ops.eh_score(corr, idx, thr, 3 * thr)]
+    ue, uh = [t.cpu().numpy() for t in ops.eh_upper(corr, c32, idx, thr, 3 * thr, xmax)]
+    assert (ue >= ce).all() and (uh >= ch).all()
+    assert (ue - ce).mean() < 0.02 * n and (uh - ch).mean() < 0.02 * n  # and they are tight
+    (cE, iE), (cH, iH), stats = ops.eh_best(corr, c32, idx, thr, 3 * thr, xmax)
+    assert (cE, iE) == (int(ce.max()), int(np.argmax(ce)))
+    assert (cH, iH) == (int(ch.max()), int(np.argmax(ch)))
+    assert stats["candidates_e"] >= 1 and stats["candidates_h"] >= 1
+    # and against the oracle for the winners themselves
+    oE, oH, _, _ = orc.score_EH_batch(x1, x2, idx_h[[iE, iH]], thr)
+    assert oE[0] == cE and oH[1] == cH
+
+
+def test_two_tier_with_many_ties(ops, dev):
+    """All-outlier data: counts are tiny and tie massively; the lowest id must still win."""
+    rng = np.random.default_rng(5)
+    n, B = 300, 5000
+    x1 = np.vstack([rng.uniform(-0.4, 0.4, (2, n)), np.ones((1, n))])
+    x2 = np.vstack([rng.uniform(-0.4, 0.4, (2, n)), np.ones((1, n))])
+    corr_h = ops.pack_corr(x1, x2)
+    corr = dev(corr_h)
+    idx = dev(rng.integers(0, n, size=(B, 12)), np.int32)
+    thr = 4e-4
+    ce, ch = [t.cpu().numpy() for t in ops.eh_score(corr, idx, thr, 3 * thr)]
+    (cE, iE), (cH, iH), stats = ops.eh_best(corr, ops.corr_to_f32(corr), idx, thr, 3 * thr, float(np.abs(corr_h).max()))
+    assert (cE, iE) == (int(ce.max()), int(np.argmax(ce)))
+    assert (cH, iH) == (int(ch.max()), int(np.argmax(ch)))
