@@ -252,11 +252,16 @@ def main():
                 "peak": PEAK_FP32_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                "traffic": None,
+                # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01b_two_tier_summary.txt):
+                # FETCH_SIZE 26118 KB x2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE 7812 KB; algorithmic bytes are
+                # 48 MB of index sets + 0.5 MB of matches read, 8 MB of counts written.
+                "traffic": (2 * 26118.1 + 7812.5) * 1024 if (n, B) == (10000, 1000000) else None,
+                "traffic_unit": "bytes per launch (PMC, measured in a separate rocprofv3 run)",
                 "kernel_ms": kern_ms,
                 "flops_per_launch": flops_per_launch,
                 "note": "not HBM- or MFMA-bound: each match is reused by every hypothesis of a workgroup; algorithmic cost "
-                "36 flops per E residual + 21 per H residual against the vector FP32 peak",
+                "36 flops per E residual + 21 per H residual against the vector FP32 peak; profiles/microbench/valu_rates "
+                "measures 131.8 TFLOP/s for a pure v_fma_f32 stream on this chip (sustained clock about 2.0 GHz)",
                 "f64_kernel": {"kernel": "eh_score_kernel", "kernel_ms": f64_ms, "achieved": flops_per_launch / (f64_ms * 1e-3) / 1e12,
                                "peak": PEAK_FP64_VALU_TFLOPS, "frac": flops_per_launch / (f64_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS},
             },

@@ -29,7 +29,7 @@ def main(d):
             "max(duration) dur from pmc_events group by name, counter_name, dispatch_id) group by name, counter_name"
         ).fetchall()
         for name, cn, v, n, dur in rows:
-            if "eh_score" in name or "t_score" in name or "argmax" in name or "lm_kernel" in name:
+            if "eh_upper" in name or "eh_score" in name or "t_score" in name or "argmax" in name or "lm_kernel" in name:
                 print(f"{name[:70]:70s} | {cn:22s} | {v:18.1f} | dispatches {n} | avg dur {dur/1e3:10.1f} us")
 
 

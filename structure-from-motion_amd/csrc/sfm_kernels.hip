@@ -107,6 +107,106 @@ __device__ __forceinline__ float round_up_f32(double v) {
   return ((double)f < v) ? nextafterf(f, INFINITY) : f;
 }
 
+struct UpperModel {
+  float E[9], H[9];
+  float kp_e, c2_e, T_h, c1_h, c0_h;
+};
+
+// solves hypothesis h in float64 and derives the float32 models and slack constants
+__device__ __forceinline__ void solve_upper_model(const double4* __restrict__ corr, const int32_t* __restrict__ row, double two_thr_e2,
+                                                  double thr_h2, double xmax, double safety, UpperModel& m) {
+  double Ed[9], Hd[9], A[9];
+  double p8[8][4], p4[4][4];
+  gather_samples<double>(corr, row, p8, p4);
+  solve_E8<double>(p8, Ed);
+  solve_H4<double>(p4, Hd);
+  to_unit_f32(Ed, m.E, A);
+  {
+    // row sums (for l = E x1) and column sums (for m = E^T x2) of |E| with |x|,|y| <= xmax
+    const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
+    const double C0 = xmax * (A[0] + A[3]) + A[6], C1 = xmax * (A[1] + A[4]) + A[7];
+    const double Es = 7.0 * kEps32 * (xmax * (R0 + R1) + R2);
+    const double eL = 6.0 * kEps32 * (R0 + R1 + C0 + C1);
+    const double rk = sqrt(two_thr_e2);
+    const double G = safety * (Es + rk * eL);
+    const double lam = rk;
+    m.kp_e = round_up_f32(two_thr_e2 * (1.0 + G / lam) * (1.0 + 16.0 * kEps32));
+    m.c2_e = round_up_f32((G * lam + G * G) * (1.0 + 16.0 * kEps32));
+  }
+  to_unit_f32(Hd, m.H, A);
+  {
+    const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
+    const double ez = 4.0 * kEps32 * R2;
+    const double Dx = 6.0 * kEps32 * (R0 + xmax * R2), Dy = 6.0 * kEps32 * (R1 + xmax * R2);
+    const double rt = sqrt(thr_h2);
+    const double G = safety * (rt * ez + Dx + Dy);
+    m.T_h = round_up_f32(thr_h2 * (1.0 + 16.0 * kEps32));
+    m.c1_h = round_up_f32(2.0 * rt * G * (1.0 + 16.0 * kEps32));
+    m.c0_h = round_up_f32(G * G * (1.0 + 16.0 * kEps32));
+  }
+}
+
+// Split form: the solver kernel leaves the float32 models in HBM as a structure of arrays
+// [24][nb] (96 bytes per hypothesis, coalesced), and the scoring kernel, which then needs only
+// ~50 VGPRs, runs at 8 waves per SIMD: float32 VALU instructions issue every 2 cycles only if
+// at least two waves are ready, which the 3 waves per SIMD of the fused kernel do not always give.
+constexpr int kModelFloats = 24;
+
+__global__ __launch_bounds__(kBlock) void eh_solve_upper_kernel(const double4* __restrict__ corr, const int32_t* __restrict__ idx, long long nb,
+                                                                double two_thr_e2, double thr_h2, double xmax, double safety,
+                                                                float* __restrict__ models) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long h = gid < nb ? gid : nb - 1;
+  UpperModel m;
+  solve_upper_model(corr, idx + 12 * h, two_thr_e2, thr_h2, xmax, safety, m);
+  if (gid < nb) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      models[(long long)i * nb + gid] = m.E[i];
+      models[(long long)(9 + i) * nb + gid] = m.H[i];
+    }
+    models[18LL * nb + gid] = m.kp_e;
+    models[19LL * nb + gid] = m.c2_e;
+    models[20LL * nb + gid] = m.T_h;
+    models[21LL * nb + gid] = m.c1_h;
+    models[22LL * nb + gid] = m.c0_h;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void eh_upper_score_kernel(const float* __restrict__ models, const float4* __restrict__ corr32, int n,
+                                                                long long nb, int* __restrict__ up_e, int* __restrict__ up_h,
+                                                                int points_per_split, int use_atomics) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long h = gid < nb ? gid : nb - 1;
+  float E[9], H[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    E[i] = models[(long long)i * nb + h];
+    H[i] = models[(long long)(9 + i) * nb + h];
+  }
+  const float kp_e = models[18LL * nb + h], c2_e = models[19LL * nb + h];
+  const float T_h = models[20LL * nb + h], c1_h = models[21LL * nb + h], c0_h = models[22LL * nb + h];
+  const int j0 = blockIdx.y * points_per_split;
+  const int j1 = min(n, j0 + points_per_split);
+  int ce = 0, ch = 0;
+#pragma clang loop vectorize(disable) interleave(disable)
+#pragma unroll 8
+  for (int j = j0; j < j1; ++j) {
+    const float4 p = corr32[j];
+    ce += epipolar_upper_f32(E, p.x, p.y, p.z, p.w, kp_e, c2_e) ? 1 : 0;
+    ch += transfer_upper_f32(H, p.x, p.y, p.z, p.w, T_h, c1_h, c0_h) ? 1 : 0;
+  }
+  if (gid < nb) {
+    if (use_atomics) {
+      atomicAdd(up_e + gid, ce);
+      atomicAdd(up_h + gid, ch);
+    } else {
+      up_e[gid] = ce;
+      up_h[gid] = ch;
+    }
+  }
+}
+
 template <bool kAllowPacked>
 __global__ __launch_bounds__(kBlock) void eh_upper_kernel(const double4* __restrict__ corr, const float4* __restrict__ corr32, int n,
                                                           const int32_t* __restrict__ idx, long long nb, double two_thr_e2, double thr_h2,
@@ -114,53 +214,25 @@ __global__ __launch_bounds__(kBlock) void eh_upper_kernel(const double4* __restr
                                                           int points_per_split, int use_atomics) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long h = gid < nb ? gid : nb - 1;
-  float E[9], H[9];
-  float kp_e, c2_e, T_h, c1_h, c0_h;
-  {
-    double Ed[9], Hd[9], A[9];
-    double p8[8][4], p4[4][4];
-    gather_samples<double>(corr, idx + 12 * h, p8, p4);
-    solve_E8<double>(p8, Ed);
-    solve_H4<double>(p4, Hd);
-    to_unit_f32(Ed, E, A);
-    {
-      // row sums (for l = E x1) and column sums (for m = E^T x2) of |E| with |x|,|y| <= xmax
-      const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
-      const double C0 = xmax * (A[0] + A[3]) + A[6], C1 = xmax * (A[1] + A[4]) + A[7];
-      const double Es = 7.0 * kEps32 * (xmax * (R0 + R1) + R2);
-      const double eL = 6.0 * kEps32 * (R0 + R1 + C0 + C1);
-      const double rk = sqrt(two_thr_e2);
-      const double G = safety * (Es + rk * eL);
-      const double lam = rk;
-      kp_e = round_up_f32(two_thr_e2 * (1.0 + G / lam) * (1.0 + 16.0 * kEps32));
-      c2_e = round_up_f32((G * lam + G * G) * (1.0 + 16.0 * kEps32));
-    }
-    to_unit_f32(Hd, H, A);
-    {
-      const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
-      const double ez = 4.0 * kEps32 * R2;
-      const double Dx = 6.0 * kEps32 * (R0 + xmax * R2), Dy = 6.0 * kEps32 * (R1 + xmax * R2);
-      const double rt = sqrt(thr_h2);
-      const double G = safety * (rt * ez + Dx + Dy);
-      T_h = round_up_f32(thr_h2 * (1.0 + 16.0 * kEps32));
-      c1_h = round_up_f32(2.0 * rt * G * (1.0 + 16.0 * kEps32));
-      c0_h = round_up_f32(G * G * (1.0 + 16.0 * kEps32));
-    }
-  }
+  UpperModel um;
+  solve_upper_model(corr, idx + 12 * h, two_thr_e2, thr_h2, xmax, safety, um);
+  const float(&E)[9] = um.E;
+  const float(&H)[9] = um.H;
+  const float kp_e = um.kp_e, c2_e = um.c2_e, T_h = um.T_h, c1_h = um.c1_h, c0_h = um.c0_h;
   const int j0 = blockIdx.y * points_per_split;
   const int j1 = min(n, j0 + points_per_split);
   int ce = 0, ch = 0;
+  int j = j0;
   if constexpr (kAllowPacked) {
 #pragma unroll 8
-    for (int j = j0; j < j1; ++j) {
+    for (; j < j1; ++j) {
       const float4 p = corr32[j];
       ce += epipolar_upper_f32(E, p.x, p.y, p.z, p.w, kp_e, c2_e) ? 1 : 0;
       ch += transfer_upper_f32(H, p.x, p.y, p.z, p.w, T_h, c1_h, c0_h) ? 1 : 0;
     }
   } else {
-#pragma clang loop vectorize(disable) interleave(disable)
 #pragma unroll 8
-    for (int j = j0; j < j1; ++j) {
+    for (; j < j1; ++j) {
       const float4 p = corr32[j];
       ce += epipolar_upper_f32(E, p.x, p.y, p.z, p.w, kp_e, c2_e) ? 1 : 0;
       ch += transfer_upper_f32(H, p.x, p.y, p.z, p.w, T_h, c1_h, c0_h) ? 1 : 0;
@@ -686,7 +758,7 @@ int sfm_corr_to_f32(const double* corr, int32_t n, float* corr32, void* stream) 
 }
 
 int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
-                     double xmax, double safety, int32_t* up_e, int32_t* up_h, void* stream) {
+                     double xmax, double safety, float* work, int32_t* up_e, int32_t* up_h, void* stream) {
   clear_stale_error();
   if (!corr || !corr32 || !idx || !up_e || !up_h || n <= 0 || nb < 0) return SFM_EINVAL;
   if (!(xmax > 0.0 && xmax < 1.0e6 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
@@ -702,15 +774,22 @@ int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const i
     e = hipMemsetAsync(up_h, 0, sizeof(int32_t) * nb, st);
     if (e != hipSuccess) return (int)e;
   }
+  const double ke = 2.0 * thr_e * thr_e, kh = thr_h * thr_h;
+  if (work) {
+    // split form: models through HBM, scoring kernel at full occupancy
+    eh_solve_upper_kernel<<<(unsigned)tiles, kBlock, 0, st>>>((const double4*)corr, idx, nb, ke, kh, xmax, safety, work);
+    int rc = check_launch();
+    if (rc) return rc;
+    eh_upper_score_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>(work, (const float4*)corr32, n, nb, up_e, up_h, pps, splits > 1);
+    return check_launch();
+  }
   static const bool unpacked = getenv("SFM_HIP_UPPER_UNPACKED") && atoi(getenv("SFM_HIP_UPPER_UNPACKED")) != 0;
   if (!unpacked)
-    eh_upper_kernel<true><<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb,
-                                                                            2.0 * thr_e * thr_e, thr_h * thr_h, xmax, safety, up_e, up_h, pps,
-                                                                            splits > 1);
+    eh_upper_kernel<true><<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb, ke, kh,
+                                                                            xmax, safety, up_e, up_h, pps, splits > 1);
   else
-    eh_upper_kernel<false><<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb,
-                                                                             2.0 * thr_e * thr_e, thr_h * thr_h, xmax, safety, up_e, up_h, pps,
-                                                                             splits > 1);
+    eh_upper_kernel<false><<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb, ke, kh,
+                                                                             xmax, safety, up_e, up_h, pps, splits > 1);
   return check_launch();
 }
 
