@@ -542,3 +542,36 @@ def run_reconstruction(relative_rotations, init_pair_dict, K, pixel_threshold):
         init_pair_dict, K, abs_rot[init_pair_dict["init_pair_indices"][0]], pixel_threshold
     )
     return X0, abs_rot, inliers
+
+
+# --------------------------------------------------------------------------
+# drivers over a correspondence provider (the reference calls cv2 here)
+# --------------------------------------------------------------------------
+
+
+def estimate_translation(K, desc_X, X0, absolute_rotations, img_paths, pixel_threshold, find_correspondences):
+    """src/estimate_translation.py:7-40 with the 2D-3D matcher passed in."""
+    out = []
+    for i in range(len(img_paths)):
+        X_corr, x_corr = find_correspondences(img_paths[i], desc_X, X0, K)
+        out.append(robust_estimate_T(x_corr, X_corr, K, absolute_rotations[i], pixel_threshold))
+    return out
+
+
+def refine_translation(K, img_paths, desc_X_inliers, X0, absolute_rotations, estimated_Ts, find_correspondences):
+    """src/refine_translation.py:7-54 with the 2D-3D matcher passed in."""
+    cams = [find_correspondences(p, desc_X_inliers, X0, K) for p in img_paths]
+    return [
+        levenberg_marquardt_algorithm(K, absolute_rotations[i], cams[i][0], cams[i][1], T, 10, 0.01)
+        for i, T in enumerate(estimated_Ts)
+    ]
+
+
+def run_geometry(K, x_pairs, init_pair_dict, img_paths, pixel_threshold, find_correspondences):
+    """run_sfm.py:59-80."""
+    R_list = estimate_R(K, x_pairs, pixel_threshold)
+    X0, abs_rot, inliers = run_reconstruction(R_list, init_pair_dict, K, pixel_threshold)
+    desc_X = init_pair_dict["init_pair_desc"]
+    est = estimate_translation(K, desc_X, X0, abs_rot, img_paths, pixel_threshold, find_correspondences)
+    ref = refine_translation(K, img_paths, desc_X[:, inliers], X0, abs_rot, est, find_correspondences)
+    return {"absolute_rotations": abs_rot, "refined_Ts": ref, "X0": X0, "inliers": inliers, "estimated_Ts": est}
