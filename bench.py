@@ -124,6 +124,35 @@ def secondary_measurements(torch, ops, _capi, synthetic, seed):
     return out
 
 
+def sweep(torch, ops, _capi, synthetic, orc, seed):
+    """Throughput of the two-tier E+H scoring step over match-set sizes (one GPU)."""
+    rows = []
+    for n, B in [(2000, 1000000), (10000, 1000000), (50000, 400000), (200000, 100000), (200000, 12500000)]:
+        sc = synthetic.two_view_scene(n=n, inlier_ratio=0.3, planar_ratio=0.5, seed=seed)
+        thr = 1.0 / sc["K"][0][0]
+        x1n = orc.normalize_K(sc["K"], sc["x1"])
+        x2n = orc.normalize_K(sc["K"], sc["x2"])
+        corr_h = ops.pack_corr(x1n, x2n)
+        corr = _capi.dev(corr_h)
+        corr32 = ops.corr_to_f32(corr)
+        xmax = float(np.abs(corr_h).max())
+        idx = torch.randint(0, n, (B, 12), dtype=torch.int32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed))
+        ce = torch.empty(B, dtype=torch.int32, device="cuda")
+        ch = torch.empty(B, dtype=torch.int32, device="cuda")
+        ops.eh_best(corr, corr32, idx, thr, 3 * thr, xmax, scratch=(ce, ch))
+        torch.cuda.synchronize()
+        reps = 3 if B * n < 5e11 else 1
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            wE, wH, st = ops.eh_best(corr, corr32, idx, thr, 3 * thr, xmax, scratch=(ce, ch))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        rows.append({"matches": n, "hypotheses": B, "ms_per_step": dt * 1e3, "evals_per_s": 2.0 * n * B / dt,
+                     "tflops_algorithmic": 57.0 * n * B / dt / 1e12, "winner_E": list(wE), "winner_H": list(wH), **st})
+        del idx, ce, ch
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +163,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=50000, help="hypotheses of the CPU baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-secondary", action="store_true", help="skip the T-RANSAC / LM / triangulation timings")
+    ap.add_argument("--sweep", action="store_true", help="only run the match-count sweep (2k..200k matches) and print it")
     args = ap.parse_args()
 
     import torch
@@ -152,6 +182,10 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     _capi.load_library()
+
+    if args.sweep:
+        print(json.dumps({"sweep": sweep(torch, ops, _capi, synthetic, orc, args.seed)}))
+        return
 
     # ---- workload: every rank holds the same matches and its own hypothesis range -----------
     n, B = args.matches, args.hyps
