@@ -146,55 +146,61 @@ __device__ __forceinline__ void solve_upper_model(const double4* __restrict__ co
   }
 }
 
-// Split form: the solver kernel leaves the float32 models in HBM as a structure of arrays
-// [24][nb] (96 bytes per hypothesis, coalesced), and the scoring kernel, which then needs only
-// ~50 VGPRs, runs at 8 waves per SIMD: float32 VALU instructions issue every 2 cycles only if
-// at least two waves are ready, which the 3 waves per SIMD of the fused kernel do not always give.
-constexpr int kModelFloats = 24;
-
-__global__ __launch_bounds__(kBlock) void eh_solve_upper_kernel(const double4* __restrict__ corr, const int32_t* __restrict__ idx, long long nb,
-                                                                double two_thr_e2, double thr_h2, double xmax, double safety,
-                                                                float* __restrict__ models) {
+// LDS-staged form of the pre-filter.  On gfx950 a float32 VALU instruction that reads an SGPR
+// operand issues at half rate (4 cycles per wave instead of 2; profiles/microbench/valu_rates),
+// which taxes 20 of the 38 instructions of a residual pair when the match comes from scalar
+// loads.  Here the workgroup stages tiles of matches in LDS (coalesced global loads, double
+// buffered, one barrier per tile) and every lane reads the current match with a broadcast
+// ds_read_b128 into VGPRs, so the whole residual runs on VGPR operands at full rate.
+template <int kTilePoints>
+__global__ __launch_bounds__(kBlock) void eh_upper_lds_kernel(const double4* __restrict__ corr, const float4* __restrict__ corr32, int n,
+                                                              const int32_t* __restrict__ idx, long long nb, double two_thr_e2, double thr_h2,
+                                                              double xmax, double safety, int* __restrict__ up_e, int* __restrict__ up_h,
+                                                              int points_per_split, int use_atomics) {
+  __shared__ float4 tile[2][kTilePoints];
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long h = gid < nb ? gid : nb - 1;
-  UpperModel m;
-  solve_upper_model(corr, idx + 12 * h, two_thr_e2, thr_h2, xmax, safety, m);
-  if (gid < nb) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      models[(long long)i * nb + gid] = m.E[i];
-      models[(long long)(9 + i) * nb + gid] = m.H[i];
-    }
-    models[18LL * nb + gid] = m.kp_e;
-    models[19LL * nb + gid] = m.c2_e;
-    models[20LL * nb + gid] = m.T_h;
-    models[21LL * nb + gid] = m.c1_h;
-    models[22LL * nb + gid] = m.c0_h;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void eh_upper_score_kernel(const float* __restrict__ models, const float4* __restrict__ corr32, int n,
-                                                                long long nb, int* __restrict__ up_e, int* __restrict__ up_h,
-                                                                int points_per_split, int use_atomics) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long h = gid < nb ? gid : nb - 1;
-  float E[9], H[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    E[i] = models[(long long)i * nb + h];
-    H[i] = models[(long long)(9 + i) * nb + h];
-  }
-  const float kp_e = models[18LL * nb + h], c2_e = models[19LL * nb + h];
-  const float T_h = models[20LL * nb + h], c1_h = models[21LL * nb + h], c0_h = models[22LL * nb + h];
+  UpperModel um;
+  solve_upper_model(corr, idx + 12 * h, two_thr_e2, thr_h2, xmax, safety, um);
+  const float(&E)[9] = um.E;
+  const float(&H)[9] = um.H;
+  const float kp_e = um.kp_e, c2_e = um.c2_e, T_h = um.T_h, c1_h = um.c1_h, c0_h = um.c0_h;
   const int j0 = blockIdx.y * points_per_split;
   const int j1 = min(n, j0 + points_per_split);
+  const float qnan = __builtin_nanf("");
+  const float4 pad = make_float4(qnan, qnan, qnan, qnan);  // a NaN match fails both tests
+  constexpr int kPerThread = kTilePoints / kBlock;
+  float4 stage[kPerThread];
+  auto fetch = [&](int base) {
+#pragma unroll
+    for (int r = 0; r < kPerThread; ++r) {
+      const int j = base + r * kBlock + (int)threadIdx.x;
+      stage[r] = (j < j1) ? corr32[j] : pad;
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < kPerThread; ++r) tile[buf][r * kBlock + threadIdx.x] = stage[r];
+  };
   int ce = 0, ch = 0;
+  fetch(j0);
+  commit(0);
+  __syncthreads();
+  int buf = 0;
+  for (int base = j0; base < j1; base += kTilePoints) {
+    const bool more = base + kTilePoints < j1;
+    if (more) fetch(base + kTilePoints);  // global loads in flight while this tile is scored
+    const float4* __restrict__ t = tile[buf];
 #pragma clang loop vectorize(disable) interleave(disable)
 #pragma unroll 8
-  for (int j = j0; j < j1; ++j) {
-    const float4 p = corr32[j];
-    ce += epipolar_upper_f32(E, p.x, p.y, p.z, p.w, kp_e, c2_e) ? 1 : 0;
-    ch += transfer_upper_f32(H, p.x, p.y, p.z, p.w, T_h, c1_h, c0_h) ? 1 : 0;
+    for (int p = 0; p < kTilePoints; ++p) {
+      const float4 q = t[p];
+      ce += epipolar_upper_f32(E, q.x, q.y, q.z, q.w, kp_e, c2_e) ? 1 : 0;
+      ch += transfer_upper_f32(H, q.x, q.y, q.z, q.w, T_h, c1_h, c0_h) ? 1 : 0;
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
   }
   if (gid < nb) {
     if (use_atomics) {
@@ -207,7 +213,6 @@ __global__ __launch_bounds__(kBlock) void eh_upper_score_kernel(const float* __r
   }
 }
 
-template <bool kAllowPacked>
 __global__ __launch_bounds__(kBlock) void eh_upper_kernel(const double4* __restrict__ corr, const float4* __restrict__ corr32, int n,
                                                           const int32_t* __restrict__ idx, long long nb, double two_thr_e2, double thr_h2,
                                                           double xmax, double safety, int* __restrict__ up_e, int* __restrict__ up_h,
@@ -222,21 +227,12 @@ __global__ __launch_bounds__(kBlock) void eh_upper_kernel(const double4* __restr
   const int j0 = blockIdx.y * points_per_split;
   const int j1 = min(n, j0 + points_per_split);
   int ce = 0, ch = 0;
-  int j = j0;
-  if constexpr (kAllowPacked) {
+  // the compiler packs two matches per v_pk_fma_f32 here (22 VALU instructions per pair instead of 38)
 #pragma unroll 8
-    for (; j < j1; ++j) {
-      const float4 p = corr32[j];
-      ce += epipolar_upper_f32(E, p.x, p.y, p.z, p.w, kp_e, c2_e) ? 1 : 0;
-      ch += transfer_upper_f32(H, p.x, p.y, p.z, p.w, T_h, c1_h, c0_h) ? 1 : 0;
-    }
-  } else {
-#pragma unroll 8
-    for (; j < j1; ++j) {
-      const float4 p = corr32[j];
-      ce += epipolar_upper_f32(E, p.x, p.y, p.z, p.w, kp_e, c2_e) ? 1 : 0;
-      ch += transfer_upper_f32(H, p.x, p.y, p.z, p.w, T_h, c1_h, c0_h) ? 1 : 0;
-    }
+  for (int j = j0; j < j1; ++j) {
+    const float4 p = corr32[j];
+    ce += epipolar_upper_f32(E, p.x, p.y, p.z, p.w, kp_e, c2_e) ? 1 : 0;
+    ch += transfer_upper_f32(H, p.x, p.y, p.z, p.w, T_h, c1_h, c0_h) ? 1 : 0;
   }
   if (gid < nb) {
     if (use_atomics) {
@@ -758,7 +754,7 @@ int sfm_corr_to_f32(const double* corr, int32_t n, float* corr32, void* stream) 
 }
 
 int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
-                     double xmax, double safety, float* work, int32_t* up_e, int32_t* up_h, void* stream) {
+                     double xmax, double safety, int32_t* up_e, int32_t* up_h, void* stream) {
   clear_stale_error();
   if (!corr || !corr32 || !idx || !up_e || !up_h || n <= 0 || nb < 0) return SFM_EINVAL;
   if (!(xmax > 0.0 && xmax < 1.0e6 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
@@ -775,21 +771,16 @@ int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const i
     if (e != hipSuccess) return (int)e;
   }
   const double ke = 2.0 * thr_e * thr_e, kh = thr_h * thr_h;
-  if (work) {
-    // split form: models through HBM, scoring kernel at full occupancy
-    eh_solve_upper_kernel<<<(unsigned)tiles, kBlock, 0, st>>>((const double4*)corr, idx, nb, ke, kh, xmax, safety, work);
-    int rc = check_launch();
-    if (rc) return rc;
-    eh_upper_score_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>(work, (const float4*)corr32, n, nb, up_e, up_h, pps, splits > 1);
-    return check_launch();
-  }
-  static const bool unpacked = getenv("SFM_HIP_UPPER_UNPACKED") && atoi(getenv("SFM_HIP_UPPER_UNPACKED")) != 0;
-  if (!unpacked)
-    eh_upper_kernel<true><<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb, ke, kh,
-                                                                            xmax, safety, up_e, up_h, pps, splits > 1);
+  // Both forms give identical counts.  The scalar-load form is the default: on MI355X this kernel runs
+  // into the power limit (fewer cycles are answered by a lower clock), and the form with fewer
+  // instruction issues and SGPR-broadcast operands is the one that finishes first.
+  static const bool lds_form = getenv("SFM_HIP_UPPER_LDS") && atoi(getenv("SFM_HIP_UPPER_LDS")) != 0;
+  if (lds_form)
+    eh_upper_lds_kernel<1024><<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb, ke, kh,
+                                                                                xmax, safety, up_e, up_h, pps, splits > 1);
   else
-    eh_upper_kernel<false><<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb, ke, kh,
-                                                                             xmax, safety, up_e, up_h, pps, splits > 1);
+    eh_upper_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb, ke, kh, xmax,
+                                                                      safety, up_e, up_h, pps, splits > 1);
   return check_launch();
 }
 

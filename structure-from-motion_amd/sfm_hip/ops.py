@@ -60,10 +60,9 @@ def corr_to_f32(corr):
     return out
 
 
-def eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, out=None, work=None):
+def eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, out=None):
     """float32 pre-filter: upper bounds (up_e, up_h) int32 [B] of the exact counts.
-    xmax: max |coordinate| over corr (host float).  work: optional float32 [24*B] scratch that
-    selects the two-kernel form (solver, then scorer at full occupancy)."""
+    xmax: max |coordinate| over corr (host float)."""
     torch = C.torch_cuda()
     lib = C.load_library()
     nb = idx.shape[0]
@@ -73,11 +72,11 @@ def eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, out=None, work=N
     else:
         ue, uh = out
     C.check(lib.sfm_eh_upper_f32(C.dptr(corr), C.dptr(corr32), corr.shape[0], C.dptr(idx), nb, float(thr_e), float(thr_h),
-                                 float(xmax), float(safety), C.dptr(work), C.dptr(ue), C.dptr(uh), C.stream_ptr()))
+                                 float(xmax), float(safety), C.dptr(ue), C.dptr(uh), C.stream_ptr()))
     return ue, uh
 
 
-def eh_best(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, scratch=None, work=None):
+def eh_best(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, scratch=None):
     """Exact first-maximum winners of a block of hypotheses, two tiers:
     float32 upper bounds for every hypothesis, float64 re-scoring of the candidates.
 
@@ -85,7 +84,7 @@ def eh_best(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, scratch=None, wor
     The result equals arg-max over sfm_eh_score_f64's counts with lowest-index tie-break."""
     torch = C.torch_cuda()
     nb = idx.shape[0]
-    ue, uh = eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety, out=scratch, work=work)
+    ue, uh = eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety, out=scratch)
     keys = torch.zeros((2,), dtype=torch.int64, device="cuda")
     argmax_count(ue, 0, keys[0:1])
     argmax_count(uh, 0, keys[1:2])
