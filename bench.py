@@ -153,6 +153,39 @@ def sweep(torch, ops, _capi, synthetic, orc, seed):
     return rows
 
 
+def e2e(torch, synthetic, orc, seed, with_cpu):
+    """End-to-end geometry (run_sfm.py:59-80) on a synthetic scene shaped like dataset 5:
+    10 cameras, dataset-5 intrinsics, a few thousand matches per consecutive pair.  The OpenCV
+    front-end is replaced by the scene's stand-in matcher on both sides; SIFT time is not part
+    of either number."""
+    from sfm_hip import pipeline, utils
+
+    sc = synthetic.multi_view_scene(n_cams=10, n_points=6000, init_pair=(4, 6), seed=seed + 5)
+    warm = synthetic.multi_view_scene(n_cams=3, n_points=400, init_pair=(0, 1), seed=seed + 6)
+    utils.find_correspondences = warm["find_correspondences"]
+    np.random.seed(seed + 10)
+    pipeline.run_geometry(warm["K"], warm["x_pairs"], warm["init_pair_dict"], warm["img_paths"], 1.0)  # library load, allocator
+    utils.find_correspondences = sc["find_correspondences"]
+    np.random.seed(seed + 11)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = pipeline.run_geometry(sc["K"], sc["x_pairs"], sc["init_pair_dict"], sc["img_paths"], 1.0)
+    torch.cuda.synchronize()
+    gpu_s = time.perf_counter() - t0
+    out = {"workload": "10 cameras, 6000 scene points, 4200 matches per consecutive pair, 4800 in the initial pair, 1 px threshold",
+           "gpu_seconds": gpu_s, "inliers_initial_pair": int(got["inliers"].sum())}
+    if with_cpu:
+        np.random.seed(seed + 11)
+        t0 = time.perf_counter()
+        ref = orc.run_geometry(sc["K"], sc["x_pairs"], sc["init_pair_dict"], sc["img_paths"], 1.0, sc["find_correspondences"])
+        out["cpu_oracle_seconds"] = time.perf_counter() - t0
+        out["max_abs_diff_R"] = float(max(np.abs(a - b).max() for a, b in zip(got["absolute_rotations"], ref["absolute_rotations"])))
+        out["max_abs_diff_T"] = float(max(np.abs(a - b).max() for a, b in zip(got["refined_Ts"], ref["refined_Ts"])))
+        out["max_rel_diff_X0"] = float(np.abs(got["X0"] - ref["X0"]).max() / np.abs(ref["X0"]).max())
+        out["inlier_masks_equal"] = bool((got["inliers"] == ref["inliers"]).all())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +196,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=50000, help="hypotheses of the CPU baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-secondary", action="store_true", help="skip the T-RANSAC / LM / triangulation timings")
+    ap.add_argument("--e2e", action="store_true", help="only run the synthetic dataset-5-shaped end-to-end geometry and print it")
+    ap.add_argument("--e2e-cpu", action="store_true", help="with --e2e: also time the NumPy oracle end to end (minutes) and compare")
     ap.add_argument("--sweep", action="store_true", help="only run the match-count sweep (2k..200k matches) and print it")
     args = ap.parse_args()
 
@@ -183,6 +218,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     _capi.load_library()
 
+    if args.e2e:
+        print(json.dumps({"e2e": e2e(torch, synthetic, orc, args.seed, args.e2e_cpu)}))
+        return
     if args.sweep:
         print(json.dumps({"sweep": sweep(torch, ops, _capi, synthetic, orc, args.seed)}))
         return
