@@ -129,6 +129,20 @@ int sfm_t_count_f64(const double* pts, int32_t m, const double* T, int64_t nb, d
  * (uint64[1]) before the first call; partial ranges and other GPUs' results combine by max. */
 int sfm_argmax_count_i32(const int32_t* counts, int64_t nb, uint64_t index_base, uint64_t* best, void* stream);
 
+/* float32 copy of packed points for sfm_t_upper_f32: pts32 float[m][8] = (RX, x, y, 0, 0, 0). */
+int sfm_pts_to_f32(const double* pts, int64_t m, float* pts32, void* stream);
+
+/* Float32 pre-filter of sfm_t_ransac_f64: UPPER BOUNDS up int32[ncam][nb] of the counts it would
+ * compute (same arguments; T solved in float64, scored in float32 with a slack derived from the
+ * float32 error bound).  rmax (HOST, double[ncam]): max |component of R X| per camera; xmax: max
+ * |x|,|y| over all cameras; safety >= 1.  Use as sfm_eh_upper_f32: exact-score the leader, then
+ * every hypothesis whose bound reaches its count (sfm_hip/ops.py:t_best). */
+int sfm_t_upper_f32(const double* pts, const float* pts32, const int64_t* cam_off, int32_t ncam, const int32_t* idx,
+                    int64_t nb, double thr, const double* rmax, double xmax, double safety, int32_t* up, void* stream);
+
+/* Row-wise sfm_argmax_count_i32 (index_base 0): best uint64[nrows] is overwritten. */
+int sfm_argmax_count_batched_i32(const int32_t* counts, int64_t nb, int32_t nrows, uint64_t* best, void* stream);
+
 /* Translations of given samples only: T_out double[nb][3] (estimate_T_2point, :80-106). */
 int sfm_t_models_f64(const double* pts, int32_t m, const int32_t* idx, int64_t nb, double* T_out, void* stream);
 

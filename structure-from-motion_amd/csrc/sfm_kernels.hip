@@ -505,6 +505,67 @@ __global__ __launch_bounds__(kBlock) void t_models_kernel(const double* __restri
   for (int i = 0; i < 3; ++i) T_out[3 * gid + i] = T[i];
 }
 
+// float32 pre-filter of the translation RANSAC: upper bounds of the counts t_score_kernel returns.
+// T is solved in float64 and rounded; points come from a float32 copy [m][8] = (RX, x, y, pad);
+// the slack covers input rounding and the float32 evaluation (see reprojection_upper_f32), with
+// |RX| <= rmax[cam] and |x|,|y| <= xmax.
+struct CamBounds {
+  double rmax[kMaxCams];
+};
+
+__global__ __launch_bounds__(kBlock) void t_upper_kernel(const double* __restrict__ pts_all, const float* __restrict__ pts32_all, CamOffsets offs,
+                                                         CamBounds bounds, const int32_t* __restrict__ idx, long long nb, double thr2,
+                                                         double xmax, double safety, int* __restrict__ up, int points_per_split,
+                                                         int use_atomics) {
+  const int cam = blockIdx.y;
+  const double* __restrict__ pts = pts_all + 6 * offs.off[cam];
+  const float* __restrict__ pts32 = pts32_all + 8 * offs.off[cam];
+  const int m = (int)(offs.off[cam + 1] - offs.off[cam]);
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long h = gid < nb ? gid : nb - 1;
+  const int32_t* pair = idx + 2 * ((long long)cam * nb + h);
+  float Tf[3], Tthr, c1, c0;
+  {
+    double T[3], x[2][3], r[2][3];
+    load_t_sample(pts, pair, x, r);
+    solve_T2<double>(x, r, pair[0] == pair[1], T);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Tf[i] = (float)T[i];
+    const double P = bounds.rmax[cam] + fmax(fabs(T[0]), fmax(fabs(T[1]), fabs(T[2])));
+    const double ez = 2.0 * kEps32 * P;
+    const double D1 = 8.0 * kEps32 * P * (1.0 + xmax);
+    const double thr = sqrt(thr2);
+    const double G = safety * (thr * ez + 1.4142135623730951 * D1);
+    Tthr = round_up_f32(thr2 * (1.0 + 16.0 * kEps32));
+    c1 = round_up_f32(2.0 * thr * G * (1.0 + 16.0 * kEps32));
+    c0 = round_up_f32(G * G * (1.0 + 16.0 * kEps32));
+  }
+  const int j0 = blockIdx.z * points_per_split;
+  const int j1 = min(m, j0 + points_per_split);
+  int c = 0;
+#pragma unroll 8
+  for (int j = j0; j < j1; ++j) {
+    const float* p = pts32 + 8LL * j;
+    c += reprojection_upper_f32(Tf[0], Tf[1], Tf[2], p[0], p[1], p[2], p[3], p[4], Tthr, c1, c0) ? 1 : 0;
+  }
+  if (gid < nb) {
+    int* dst = up + (long long)cam * nb + gid;
+    if (use_atomics)
+      atomicAdd(dst, c);
+    else
+      *dst = c;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void pts_to_f32_kernel(const double* __restrict__ pts, long long m, float* __restrict__ pts32) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) pts32[8 * j + i] = (float)pts[6 * j + i];
+#pragma unroll
+  for (int i = 5; i < 8; ++i) pts32[8 * j + i] = 0.0f;
+}
+
 // inlier counts of given translations over one camera's points (one translation per lane)
 __global__ __launch_bounds__(kBlock) void t_count_kernel(const double* __restrict__ pts, int m, const double* __restrict__ Ts, long long nb,
                                                          double thr2, int* __restrict__ counts) {
@@ -940,6 +1001,56 @@ int sfm_argmax_count_i32(const int32_t* counts, int64_t nb, uint64_t index_base,
   const long long tiles = (nb + kBlock - 1) / kBlock;
   const int ablocks = (int)(tiles < 1024 ? tiles : 1024);
   argmax_kernel<<<dim3(ablocks, 1), kBlock, 0, (hipStream_t)stream>>>(counts, nb, index_base, (unsigned long long*)best);
+  return check_launch();
+}
+
+int sfm_pts_to_f32(const double* pts, int64_t m, float* pts32, void* stream) {
+  clear_stale_error();
+  if (!pts || !pts32 || m < 0) return SFM_EINVAL;
+  if (m == 0) return 0;
+  pts_to_f32_kernel<<<div_up(m, kBlock), kBlock, 0, (hipStream_t)stream>>>(pts, m, pts32);
+  return check_launch();
+}
+
+int sfm_t_upper_f32(const double* pts, const float* pts32, const int64_t* cam_off, int32_t ncam, const int32_t* idx, int64_t nb, double thr,
+                    const double* rmax, double xmax, double safety, int32_t* up, void* stream) {
+  clear_stale_error();
+  if (!pts || !pts32 || !idx || !up || !rmax || nb <= 0) return SFM_EINVAL;
+  if (!(xmax > 0.0 && xmax < 1.0e6 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
+  CamOffsets offs;
+  int rc = fill_offsets(cam_off, ncam, &offs);
+  if (rc) return rc;
+  CamBounds bounds;
+  int mmax = 0;
+  for (int c = 0; c < ncam; ++c) {
+    const int m = (int)(offs.off[c + 1] - offs.off[c]);
+    if (m <= 0 || !(rmax[c] >= 0.0 && rmax[c] < 1.0e12)) return SFM_EINVAL;
+    bounds.rmax[c] = rmax[c];
+    mmax = m > mmax ? m : mmax;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const long long tiles = (nb + kBlock - 1) / kBlock;
+  if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
+  const int splits = choose_splits(tiles * ncam, mmax);
+  const int pps = div_up(mmax, splits);
+  if (splits > 1) {
+    hipError_t e = hipMemsetAsync(up, 0, sizeof(int32_t) * nb * ncam, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  t_upper_kernel<<<dim3((unsigned)tiles, ncam, splits), kBlock, 0, st>>>(pts, pts32, offs, bounds, idx, nb, thr * thr, xmax, safety, up, pps,
+                                                                         splits > 1);
+  return check_launch();
+}
+
+int sfm_argmax_count_batched_i32(const int32_t* counts, int64_t nb, int32_t nrows, uint64_t* best, void* stream) {
+  clear_stale_error();
+  if (!counts || !best || nb <= 0 || nrows <= 0 || nrows > 65535 || (uint64_t)nb > 0xFFFFFFFFull) return SFM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(best, 0, sizeof(uint64_t) * nrows, st);
+  if (e != hipSuccess) return (int)e;
+  const long long tiles = (nb + kBlock - 1) / kBlock;
+  const int ablocks = (int)(tiles < 256 ? tiles : 256);
+  argmax_kernel<<<dim3(ablocks, nrows), kBlock, 0, st>>>(counts, nb, 0ull, (unsigned long long*)best);
   return check_launch();
 }
 

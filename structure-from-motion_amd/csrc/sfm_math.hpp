@@ -342,6 +342,16 @@ SFM_FN bool transfer_upper_f32(const float (&H)[9], float x1, float y1, float x2
   return d2 < fma(T, hz * hz, fma(c1, fabs(hz), c0));
 }
 
+// Upper-bound form of the reprojection test below, float32:  |d| < thr |pz| with |d - d_true| <= D and
+// |pz - pz_true| <= ez implies d^2 < T pz^2 + c1 |pz| + c0 (c1 = 2 thr G, c0 = G^2, G = thr ez + D).
+SFM_FN bool reprojection_upper_f32(float tx, float ty, float tz, float rx, float ry, float rz, float u, float v, float T, float c1, float c0) {
+  const float px = rx + tx, py = ry + ty, pz = rz + tz;
+  const float dx = fma(-u, pz, px);
+  const float dy = fma(-v, pz, py);
+  const float d2 = fma(dx, dx, dy * dy);
+  return d2 < fma(T, pz * pz, fma(c1, fabs(pz), c0));
+}
+
 // Reprojection test of src/estimate_translation.py:123-127 with RX precomputed:
 // |pi(RX + T) - x| < thr  as  |(RX+T)_{xy} - x (RX+T)_z|^2 < thr^2 (RX+T)_z^2.
 template <typename T>

@@ -35,6 +35,9 @@ _SIGS = {
     "sfm_t_ransac_f64": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _P, _P, _P, _P]),
     "sfm_t_count_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _c.c_double, _P, _P]),
     "sfm_argmax_count_i32": (_c.c_int, [_P, _c.c_int64, _c.c_uint64, _P, _P]),
+    "sfm_pts_to_f32": (_c.c_int, [_P, _c.c_int64, _P, _P]),
+    "sfm_t_upper_f32": (_c.c_int, [_P, _P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _P, _c.c_double, _c.c_double, _P, _P]),
+    "sfm_argmax_count_batched_i32": (_c.c_int, [_P, _c.c_int64, _c.c_int32, _P, _P]),
     "sfm_t_models_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _P, _P]),
     "sfm_lm_translation_f64": (_c.c_int, [_P, _P, _P, _c.c_int32, _P, _c.c_int32, _c.c_double, _P, _P, _P, _P]),
 }

@@ -228,6 +228,71 @@ def t_ransac(pts, cam_sizes, idx, thr):
     return best, T, counts
 
 
+def pts_to_f32(pts):
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    out = _empty((pts.shape[0], 8), torch.float32)
+    C.check(lib.sfm_pts_to_f32(C.dptr(pts), pts.shape[0], C.dptr(out), C.stream_ptr()))
+    return out
+
+
+def t_upper(pts, pts32, cam_sizes, idx, thr, rmax, xmax, safety=2.0):
+    """float32 pre-filter of t_ransac: upper bounds int32 [ncam][B]."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    ncam, nb = idx.shape[0], idx.shape[1]
+    off = _offsets(cam_sizes)
+    rm = np.ascontiguousarray(rmax, dtype=np.float64)
+    up = _empty((ncam, nb), torch.int32)
+    C.check(lib.sfm_t_upper_f32(C.dptr(pts), C.dptr(pts32), C.hptr(off), ncam, C.dptr(idx), nb, float(thr), C.hptr(rm), float(xmax),
+                                float(safety), C.dptr(up), C.stream_ptr()))
+    return up
+
+
+def argmax_count_batched(counts):
+    """counts int32 [R][B] -> packed keys int64 [R] (first maximum of every row)."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    best = _empty((counts.shape[0],), torch.int64)
+    C.check(lib.sfm_argmax_count_batched_i32(C.dptr(counts), counts.shape[1], counts.shape[0], C.dptr(best), C.stream_ptr()))
+    return best
+
+
+def t_best(pts, pts32, cam_sizes, idx, thr, rmax, xmax, safety=2.0):
+    """Exact winners of the translation RANSAC of every camera, two tiers (float32 bounds for all
+    hypotheses, float64 re-score of the candidates).  Returns (count [ncam], index [ncam], T [ncam][3])
+    as host arrays, equal to what t_ransac returns."""
+    torch = C.torch_cuda()
+    ncam, nb = idx.shape[0], idx.shape[1]
+    up = t_upper(pts, pts32, cam_sizes, idx, thr, rmax, xmax, safety)
+    lead = 0xFFFFFFFF - (argmax_count_batched(up) & 0xFFFFFFFF)  # [ncam] ids of the largest bounds
+    rows = torch.arange(ncam, device="cuda")
+    lead_idx = idx[rows, lead].reshape(ncam, 1, 2).contiguous()
+    best, T, _ = t_ransac(pts, cam_sizes, lead_idx, thr)
+    floor = best >> 32  # exact count of every leader
+    mask = up >= floor.to(torch.int32)[:, None]
+    ncand = mask.sum(dim=1)
+    info = torch.cat([lead, floor, ncand]).cpu().numpy()
+    lead_h, floor_h, ncand_h = info[:ncam], info[ncam : 2 * ncam], info[2 * ncam :]
+    count = floor_h.astype(np.int64).copy()
+    index = lead_h.astype(np.int64).copy()
+    T_out = T
+    kmax = int(ncand_h.max())
+    if kmax > 1:
+        # candidate ids per camera, ascending, padded with the leader (already present, so a padded
+        # duplicate can never beat the first occurrence)
+        order = torch.argsort(mask.to(torch.int8), dim=1, descending=True, stable=True)[:, :kmax]
+        pos = torch.arange(kmax, device="cuda")[None, :]
+        cand = torch.where(pos < ncand[:, None], order, lead[:, None])
+        cand_idx = idx[rows[:, None], cand].contiguous()
+        best2, T_out, _ = t_ransac(pts, cam_sizes, cand_idx, thr)
+        c2, p2 = decode_best(best2.cpu().numpy())
+        cand_h = cand.cpu().numpy()
+        count = c2
+        index = cand_h[np.arange(ncam), p2].astype(np.int64)
+    return count, index, T_out.cpu().numpy()
+
+
 def t_count(pts, T, thr):
     """pts float64 [M][6]; T float64 [B][3] -> counts int32 [B]."""
     torch = C.torch_cuda()

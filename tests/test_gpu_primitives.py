@@ -226,3 +226,31 @@ def test_two_tier_with_many_ties(ops, dev):
     (cE, iE), (cH, iH), stats = ops.eh_best(corr, ops.corr_to_f32(corr), idx, thr, 3 * thr, float(np.abs(corr_h).max()))
     assert (cE, iE) == (int(ce.max()), int(np.argmax(ce)))
     assert (cH, iH) == (int(ch.max()), int(np.argmax(ch)))
+
+
+def test_t_two_tier_matches_f64(ops, dev):
+    """float32 bounds of the translation RANSAC never undercount; t_best equals t_ransac
+    (count, first-maximum index and T) for a ragged batch incl. a tie-heavy camera."""
+    import torch
+
+    cams = [synthetic.resection_scene(m=m, outlier_ratio=o, seed=s) for m, o, s in ((700, 0.5, 1), (257, 0.2, 2), (3000, 0.7, 3), (64, 0.95, 4))]
+    sizes = [c["x_norm"].shape[1] for c in cams]
+    B = 20000
+    rng = np.random.default_rng(0)
+    idx = dev(np.stack([rng.integers(0, m, (B, 2)) for m in sizes]), np.int32)
+    pts = torch.cat([ops.pack_points(dev(c["R"].ravel()), dev(c["X"]), dev(c["x_norm"])) for c in cams])
+    pts32 = ops.pts_to_f32(pts)
+    thr = 4.0 / cams[0]["K"][0][0]
+    ph = pts.cpu().numpy()
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    rmax = [np.abs(ph[off[c] : off[c + 1], :3]).max() for c in range(len(cams))]
+    xmax = float(np.abs(ph[:, 3:5]).max())
+    best, T, counts = ops.t_ransac(pts, sizes, idx, thr)
+    up = ops.t_upper(pts, pts32, sizes, idx, thr, rmax, xmax)
+    assert bool((up >= counts).all())
+    assert float((up - counts).float().mean()) < 0.5
+    cnt, ind = ops.decode_best(best.cpu().numpy())
+    c2, i2, T2 = ops.t_best(pts, pts32, sizes, idx, thr, rmax, xmax)
+    np.testing.assert_array_equal(c2, cnt)
+    np.testing.assert_array_equal(i2, ind)
+    np.testing.assert_allclose(T2, T.cpu().numpy(), rtol=0, atol=0)
