@@ -319,7 +319,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 pre-filter + f64 solvers and re-score",
+            "dtype": "f32+f64",  # float32 pre-filter; float64 solvers and exact re-score of the candidates
             "data": "synthetic",
             "config": {
                 "workload": f"synthetic two-view E+H RANSAC: {n} matches, 30% inliers, {B} hypotheses per GPU "

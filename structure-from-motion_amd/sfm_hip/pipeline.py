@@ -35,3 +35,23 @@ def run_geometry(K, x_pairs, init_pair_dict, img_paths, pixel_threshold):
         "inliers": inliers,
         "estimated_Ts": estimated_Ts,
     }
+
+
+def triangulate_point_cloud(sfm_data_dict):
+    """The point cloud the reference's visualiser draws (utils.py:140-156 there): for every
+    consecutive camera pair, DLT triangulation of its matches with the PIXEL cameras K[R|T] and
+    pixel coordinates, followed by filter_3D_points applied to the 4xN array as the reference
+    applies it (row-wise; in practice it keeps everything).  Returns one 4xN array per pair."""
+    from .utils import filter_3D_points, triangulate_3D_point_DLT
+
+    K = np.asarray(sfm_data_dict["K"], float)
+    R = sfm_data_dict["absolute_rotations"]
+    T = sfm_data_dict["refined_Ts"]
+    x_pairs = sfm_data_dict["x_pairs"]
+    clouds = []
+    for i in range(sfm_data_dict["nr_images"] - 1):
+        P1 = K @ np.hstack((R[i], np.reshape(T[i], (3, 1))))
+        P2 = K @ np.hstack((R[i + 1], np.reshape(T[i + 1], (3, 1))))
+        X = triangulate_3D_point_DLT([P1, P2], [x_pairs[2 * i], x_pairs[2 * i + 1]])
+        clouds.append(filter_3D_points(X))
+    return clouds
