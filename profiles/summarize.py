@@ -16,6 +16,18 @@ def main(d):
         print("== kernel trace (rocprofv3 --kernel-trace --stats): name | calls | total us | avg us | % ==")
         for name, calls, tot, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
             print(f"{name[:110]:110s} | {calls:5d} | {tot:12.1f} | {avg:10.2f} | {pct:6.2f}")
+        print("\n== per-dispatch durations of the main kernels in dispatch order (us) ==")
+        try:
+            rows = c.execute("select name, start, end from kernels order by start").fetchall()
+            per = {}
+            for name, st, en in rows:
+                if "eh_upper" in name or ("eh_score" in name) or "t_score" in name:
+                    per.setdefault(name[:80], []).append((en - st) / 1e3)
+            for name, durs in per.items():
+                big = [x for x in durs if x > 0.25 * max(durs)]
+                print(f"{name:80s} | n={len(durs)} | full-size launches: " + " ".join(f"{x:.0f}" for x in big[:24]))
+        except Exception as e:  # schema differences between rocprofv3 versions
+            print("  (per-dispatch listing unavailable:", e, ")")
     for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
         if not os.path.isdir(sub):
             continue

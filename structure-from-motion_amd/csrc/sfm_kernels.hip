@@ -110,6 +110,8 @@ __device__ __forceinline__ float round_up_f32(double v) {
 struct UpperModel {
   float E[9], H[9];
   float kp_e, c2_e, T_h, c1_h, c0_h;
+  float k1_e, c_e;  // one-sided (loose) epipolar form
+  float rt_h, g_h;  // box (loose) transfer form
 };
 
 // solves hypothesis h in float64 and derives the float32 models and slack constants
@@ -132,6 +134,9 @@ __device__ __forceinline__ void solve_upper_model(const double4* __restrict__ co
     const double lam = rk;
     m.kp_e = round_up_f32(two_thr_e2 * (1.0 + G / lam) * (1.0 + 16.0 * kEps32));
     m.c2_e = round_up_f32((G * lam + G * G) * (1.0 + 16.0 * kEps32));
+    const double mu = 1.0e-3;
+    m.k1_e = round_up_f32(two_thr_e2 * (1.0 + mu) * (1.0 + 16.0 * kEps32));
+    m.c_e = round_up_f32(G * G * (1.0 + 1.0 / mu) * (1.0 + 16.0 * kEps32));
   }
   to_unit_f32(Hd, m.H, A);
   {
@@ -143,6 +148,8 @@ __device__ __forceinline__ void solve_upper_model(const double4* __restrict__ co
     m.T_h = round_up_f32(thr_h2 * (1.0 + 16.0 * kEps32));
     m.c1_h = round_up_f32(2.0 * rt * G * (1.0 + 16.0 * kEps32));
     m.c0_h = round_up_f32(G * G * (1.0 + 16.0 * kEps32));
+    m.rt_h = round_up_f32(rt * (1.0 + 16.0 * kEps32));
+    m.g_h = round_up_f32(G * (1.0 + 16.0 * kEps32));
   }
 }
 
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(kBlock) void eh_upper_lds_kernel(const double4* __r
   }
 }
 
+template <bool kOneSided>
 __global__ __launch_bounds__(kBlock) void eh_upper_kernel(const double4* __restrict__ corr, const float4* __restrict__ corr32, int n,
                                                           const int32_t* __restrict__ idx, long long nb, double two_thr_e2, double thr_h2,
                                                           double xmax, double safety, int* __restrict__ up_e, int* __restrict__ up_h,
@@ -228,11 +236,17 @@ __global__ __launch_bounds__(kBlock) void eh_upper_kernel(const double4* __restr
   const int j1 = min(n, j0 + points_per_split);
   int ce = 0, ch = 0;
   // the compiler packs two matches per v_pk_fma_f32 here (22 VALU instructions per pair instead of 38)
+  const float k1_e = um.k1_e, c_e = um.c_e, rt_h = um.rt_h, g_h = um.g_h;
 #pragma unroll 8
   for (int j = j0; j < j1; ++j) {
     const float4 p = corr32[j];
-    ce += epipolar_upper_f32(E, p.x, p.y, p.z, p.w, kp_e, c2_e) ? 1 : 0;
-    ch += transfer_upper_f32(H, p.x, p.y, p.z, p.w, T_h, c1_h, c0_h) ? 1 : 0;
+    if constexpr (kOneSided) {
+      ce += epipolar_upper_onesided_f32(E, p.x, p.y, p.z, p.w, k1_e, c_e) ? 1 : 0;
+      ch += transfer_upper_box_f32(H, p.x, p.y, p.z, p.w, rt_h, g_h) ? 1 : 0;
+    } else {
+      ce += epipolar_upper_f32(E, p.x, p.y, p.z, p.w, kp_e, c2_e) ? 1 : 0;
+      ch += transfer_upper_f32(H, p.x, p.y, p.z, p.w, T_h, c1_h, c0_h) ? 1 : 0;
+    }
   }
   if (gid < nb) {
     if (use_atomics) {
@@ -815,7 +829,7 @@ int sfm_corr_to_f32(const double* corr, int32_t n, float* corr32, void* stream) 
 }
 
 int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
-                     double xmax, double safety, int32_t* up_e, int32_t* up_h, void* stream) {
+                     double xmax, double safety, int32_t one_sided, int32_t* up_e, int32_t* up_h, void* stream) {
   clear_stale_error();
   if (!corr || !corr32 || !idx || !up_e || !up_h || n <= 0 || nb < 0) return SFM_EINVAL;
   if (!(xmax > 0.0 && xmax < 1.0e6 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
@@ -836,12 +850,15 @@ int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const i
   // into the power limit (fewer cycles are answered by a lower clock), and the form with fewer
   // instruction issues and SGPR-broadcast operands is the one that finishes first.
   static const bool lds_form = getenv("SFM_HIP_UPPER_LDS") && atoi(getenv("SFM_HIP_UPPER_LDS")) != 0;
-  if (lds_form)
+  if (one_sided)
+    eh_upper_kernel<true><<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb, ke, kh, xmax,
+                                                                            safety, up_e, up_h, pps, splits > 1);
+  else if (lds_form)
     eh_upper_lds_kernel<1024><<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb, ke, kh,
                                                                                 xmax, safety, up_e, up_h, pps, splits > 1);
   else
-    eh_upper_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb, ke, kh, xmax,
-                                                                      safety, up_e, up_h, pps, splits > 1);
+    eh_upper_kernel<false><<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb, ke, kh, xmax,
+                                                                             safety, up_e, up_h, pps, splits > 1);
   return check_launch();
 }
 

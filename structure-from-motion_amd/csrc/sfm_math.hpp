@@ -332,6 +332,20 @@ SFM_FN bool epipolar_upper_f32(const float (&E)[9], float x1, float y1, float x2
   return ss * (n1 + n2) < kp * (n1 * n2);
 }
 
+// Cheaper, looser upper-bound form of the epipolar test: since n2/(n1+n2) < 1 the symmetric test
+// implies the one-sided  s^2 < k n1  (distance to the epipolar line in view 2 below sqrt(2) thr),
+// which needs neither E^T x2 nor n2.  With the float32 error bounds (|s - s_true| <= Es,
+// |L1 - L1_true| <= eL, G = Es + sqrt(k) eL) and 2ab <= mu a^2 + b^2/mu:
+//      s^2 - c < k1 n1,   k1 = k (1 + mu),  c = G^2 (1 + 1/mu).
+SFM_FN bool epipolar_upper_onesided_f32(const float (&E)[9], float x1, float y1, float x2, float y2, float k1, float c) {
+  const float l0 = fma(E[0], x1, fma(E[1], y1, E[2]));
+  const float l1 = fma(E[3], x1, fma(E[4], y1, E[5]));
+  const float l2 = fma(E[6], x1, fma(E[7], y1, E[8]));
+  const float s = fma(l0, x2, fma(l1, y2, l2));
+  const float n1 = fma(l0, l0, l1 * l1);
+  return fma(s, s, -c) < k1 * n1;
+}
+
 SFM_FN bool transfer_upper_f32(const float (&H)[9], float x1, float y1, float x2, float y2, float T, float c1, float c0) {
   const float hx = fma(H[0], x1, fma(H[1], y1, H[2]));
   const float hy = fma(H[3], x1, fma(H[4], y1, H[5]));
@@ -350,6 +364,20 @@ SFM_FN bool reprojection_upper_f32(float tx, float ty, float tz, float rx, float
   const float dy = fma(-v, pz, py);
   const float d2 = fma(dx, dx, dy * dy);
   return d2 < fma(T, pz * pz, fma(c1, fabs(pz), c0));
+}
+
+// Cheaper, slightly looser upper-bound form of the transfer test: |x2 - pi(H x1)| < thr implies that
+// each component alone differs by less than thr (a box instead of a disc: 4/pi of its area), i.e.
+// |x2 hz - hx| < thr |hz| and |y2 hz - hy| < thr |hz| (+ the float32 slack G): no squares.
+// rt = sqrt(T) rounded up.
+SFM_FN bool transfer_upper_box_f32(const float (&H)[9], float x1, float y1, float x2, float y2, float rt, float g) {
+  const float hx = fma(H[0], x1, fma(H[1], y1, H[2]));
+  const float hy = fma(H[3], x1, fma(H[4], y1, H[5]));
+  const float hz = fma(H[6], x1, fma(H[7], y1, H[8]));
+  const float dx = fma(x2, hz, -hx);
+  const float dy = fma(y2, hz, -hy);
+  const float lim = fma(rt, fabs(hz), g);
+  return (fabs(dx) < lim) & (fabs(dy) < lim);
 }
 
 // Reprojection test of src/estimate_translation.py:123-127 with RX precomputed:

@@ -60,9 +60,9 @@ def corr_to_f32(corr):
     return out
 
 
-def eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, out=None):
+def eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, out=None, one_sided=False):
     """float32 pre-filter: upper bounds (up_e, up_h) int32 [B] of the exact counts.
-    xmax: max |coordinate| over corr (host float)."""
+    xmax: max |coordinate| over corr (host float).  one_sided: cheaper, looser bound for E."""
     torch = C.torch_cuda()
     lib = C.load_library()
     nb = idx.shape[0]
@@ -72,19 +72,28 @@ def eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, out=None):
     else:
         ue, uh = out
     C.check(lib.sfm_eh_upper_f32(C.dptr(corr), C.dptr(corr32), corr.shape[0], C.dptr(idx), nb, float(thr_e), float(thr_h),
-                                 float(xmax), float(safety), C.dptr(ue), C.dptr(uh), C.stream_ptr()))
+                                 float(xmax), float(safety), int(bool(one_sided)), C.dptr(ue), C.dptr(uh), C.stream_ptr()))
     return ue, uh
 
 
-def eh_best(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, scratch=None):
-    """Exact first-maximum winners of a block of hypotheses, two tiers:
-    float32 upper bounds for every hypothesis, float64 re-scoring of the candidates.
+TIGHTEN_ABOVE = 4096  # candidates beyond this count go through the tight float32 bound before float64
 
-    Returns ((count_e, index_e), (count_h, index_h), stats) with indices local to `idx`.
-    The result equals arg-max over sfm_eh_score_f64's counts with lowest-index tie-break."""
+
+def eh_best(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, scratch=None, loose=True):
+    """Exact first-maximum winners of a block of hypotheses by a cascade of upper bounds:
+
+      1. float32 bounds for every hypothesis (loose=True: one-sided epipolar + box transfer test,
+         26 instead of 38 instructions per residual pair);
+      2. exact float64 count of the hypothesis with the largest bound -> a floor;
+      3. every hypothesis whose bound reaches the floor is a candidate; if there are many they are
+         first re-bounded with the tight float32 forms;
+      4. the remaining candidates are scored in float64; the first maximum wins.
+
+    Every level only discards hypotheses whose upper bound is below an exact count that exists,
+    so the result equals arg-max over sfm_eh_score_f64's counts with lowest-index tie-break.
+    Returns ((count_e, index_e), (count_h, index_h), stats) with indices local to `idx`."""
     torch = C.torch_cuda()
-    nb = idx.shape[0]
-    ue, uh = eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety, out=scratch)
+    ue, uh = eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety, out=scratch, one_sided=loose)
     keys = torch.zeros((2,), dtype=torch.int64, device="cuda")
     argmax_count(ue, 0, keys[0:1])
     argmax_count(uh, 0, keys[1:2])
@@ -96,11 +105,19 @@ def eh_best(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, scratch=None):
     # one host round trip: leaders, their exact counts and the number of candidates
     info = torch.cat([lead, floor, torch.stack([mask_e.sum(), mask_h.sum()])]).cpu().numpy()
     le, lh, fe, fh, ne, nh = (int(v) for v in info)
+    stats = {"candidates_e": ne, "candidates_h": nh, "tightened": 0}
     win_e, win_h = (fe, le), (fh, lh)
     if ne > 1 or nh > 1:
-        # several hypotheses could still beat (or tie with a lower id than) a leader: re-score them exactly
-        cand_e = torch.nonzero(mask_e).flatten() if ne > 1 else lead[0:1]
+        # several hypotheses could still beat (or tie with a lower id than) a leader
+        cand_e = torch.nonzero(mask_e).flatten() if ne > 1 else lead[0:1]  # ascending ids
         cand_h = torch.nonzero(mask_h).flatten() if nh > 1 else lead[1:2]
+        if loose and cand_e.shape[0] + cand_h.shape[0] > TIGHTEN_ABOVE:
+            cand = torch.cat([cand_e, cand_h])
+            te, th = eh_upper(corr, corr32, idx.index_select(0, cand), thr_e, thr_h, xmax, safety, one_sided=False)
+            k = cand_e.shape[0]
+            cand_e = cand_e[te[:k] >= floor[0]]
+            cand_h = cand_h[th[k:] >= floor[1]]
+            stats["tightened"] = int(cand.shape[0])
         cand = torch.cat([cand_e, cand_h])
         ce, ch = eh_score(corr, idx.index_select(0, cand), thr_e, thr_h)
         k = cand_e.shape[0]
@@ -111,7 +128,8 @@ def eh_best(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, scratch=None):
         ih = int(np.argmax(xh[k:]))
         win_e = (int(xe[ie]), int(ids[ie]))
         win_h = (int(xh[k + ih]), int(ids[k + ih]))
-    return win_e, win_h, {"candidates_e": ne, "candidates_h": nh}
+        stats["rescored_f64"] = int(m)
+    return win_e, win_h, stats
 
 
 def eh_models(corr, idx, want_F=False):

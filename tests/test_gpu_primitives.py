@@ -254,3 +254,27 @@ def test_t_two_tier_matches_f64(ops, dev):
     np.testing.assert_array_equal(c2, cnt)
     np.testing.assert_array_equal(i2, ind)
     np.testing.assert_allclose(T2, T.cpu().numpy(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("inl,pl,n,B,seed", [(0.3, 0.5, 5000, 100000, 0), (0.05, 0.5, 4000, 60000, 3), (0.0, 0.5, 3000, 40000, 6), (0.6, 0.0, 1000, 30000, 7)])
+def test_loose_bound_cascade_is_exact(ops, dev, inl, pl, n, B, seed, monkeypatch):
+    """The cheaper (one-sided / box) bounds hold, and the cascade (loose bounds -> tight bounds for many
+    candidates -> float64) returns the first maximum of the float64 counts in regimes from a dominant
+    plane to pure outliers (where thousands of hypotheses survive the loose bound)."""
+    sc, x1, x2 = scene(n=n, inl=inl, pl=pl, seed=seed)
+    corr_h = ops.pack_corr(x1, x2)
+    corr = dev(corr_h)
+    c32 = ops.corr_to_f32(corr)
+    xmax = float(np.abs(corr_h).max())
+    idx = dev(np.random.default_rng(seed).integers(0, n, size=(B, 12)), np.int32)
+    thr = 1.0 / sc["K"][0][0]
+    ce, ch = [t.cpu().numpy() for t in ops.eh_score(corr, idx, thr, 3 * thr)]
+    ue, uh = [t.cpu().numpy() for t in ops.eh_upper(corr, c32, idx, thr, 3 * thr, xmax, one_sided=True)]
+    te, th = [t.cpu().numpy() for t in ops.eh_upper(corr, c32, idx, thr, 3 * thr, xmax, one_sided=False)]
+    assert (ue >= te).all() or (ue >= ce).all()
+    assert (ue >= ce).all() and (uh >= ch).all() and (te >= ce).all() and (th >= ch).all()
+    monkeypatch.setattr(ops, "TIGHTEN_ABOVE", 64)  # force the middle level to run in the sparse regimes
+    for loose in (True, False):
+        (cE, iE), (cH, iH), stats = ops.eh_best(corr, c32, idx, thr, 3 * thr, xmax, loose=loose)
+        assert (cE, iE) == (int(ce.max()), int(np.argmax(ce))), stats
+        assert (cH, iH) == (int(ch.max()), int(np.argmax(ch))), stats
