@@ -97,7 +97,8 @@ int sfm_chirality4_f64(const double* P2s, const double* corr, const uint8_t* mas
 
 /* Homography -> two (R,t) solutions, src/ransac_algorithm.py:332-403 including the sign vote
  * over all n correspondences (:359-361); H itself is not modified.
- * out: double[42] = R1[9] t1[3] R2[9] t2[3] Ea[9] Eb[9] with E = [t]x R (:129-130). */
+ * out: double[43] = R1[9] t1[3] R2[9] t2[3] Ea[9] Eb[9] with E = [t]x R (:129-130), then 1.0 if the
+ * vote negated H (the reference negates its argument in place in that case) else 0.0. */
 int sfm_homography_to_rt_f64(const double* H, const double* corr, int32_t n, double* out, void* stream);
 
 /* DLT triangulation of m points, src/utils.py:17-36.  P1, P2: double[12]; x1, x2: the first two

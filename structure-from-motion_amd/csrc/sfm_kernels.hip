@@ -424,6 +424,7 @@ __global__ __launch_bounds__(1024) void homography_to_rt_kernel(const double* __
       out[9 + i] = t1[i];
       out[21 + i] = t2[i];
     }
+    out[42] = flip ? 1.0 : 0.0;
   }
 }
 

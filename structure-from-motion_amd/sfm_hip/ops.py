@@ -201,7 +201,7 @@ def chirality4(P2s, corr, mask=None):
 def homography_to_rt(H, corr):
     torch = C.torch_cuda()
     lib = C.load_library()
-    out = _empty((42,), torch.float64)
+    out = _empty((43,), torch.float64)
     C.check(lib.sfm_homography_to_rt_f64(C.dptr(H), C.dptr(corr), corr.shape[0], C.dptr(out), C.stream_ptr()))
     return out
 

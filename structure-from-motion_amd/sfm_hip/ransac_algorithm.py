@@ -275,12 +275,8 @@ def homography_to_RT(H, x1, x2):
     corr = C.dev(ops.pack_corr(x1, x2))
     Hd = C.dev(np.asarray(H, np.float64).reshape(9))
     out = ops.homography_to_rt(Hd, corr).cpu().numpy()
-    x1h = np.asarray(x1, np.float64)
-    x2h = np.asarray(x2, np.float64)
-    if isinstance(H, np.ndarray):
-        positives = np.sum(np.sum(x2h * (H @ x1h), axis=0) > 0)
-        if positives < x1h.shape[1] / 2:
-            H *= -1
+    if isinstance(H, np.ndarray) and out[42] != 0.0:
+        H *= -1  # the kernel's sign vote said so
     return out[:9].reshape(3, 3), out[9:12].copy(), out[12:21].reshape(3, 3), out[21:24].copy()
 
 

@@ -177,3 +177,20 @@ def test_triangulate_api_and_edge_cases(sfm, golden):
         bad = x1.copy()
         bad[2, 0] = 2.0
         ops.pack_corr(bad, x2)
+
+
+def test_homography_to_RT_negates_its_argument_like_the_reference(sfm, golden):
+    from sfm_hip import ransac_algorithm as ra
+
+    g = golden("eh_scoring.npz")
+    d = golden("decomp.npz")
+    sc = two_view(g["scene"])
+    x1 = orc.normalize_K(sc["K"], sc["x1"])
+    x2 = orc.normalize_K(sc["K"], sc["x2"])
+    for sign in (1.0, -1.0):
+        Hm = sign * d["H"][0].copy()
+        before = Hm.copy()
+        ra.homography_to_RT(Hm, x1, x2)
+        positives = np.sum(np.sum(x2 * (before @ x1), axis=0) > 0)
+        expect = -before if positives < x1.shape[1] / 2 else before
+        np.testing.assert_array_equal(Hm, expect)
