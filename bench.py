@@ -155,17 +155,19 @@ def sweep(torch, ops, _capi, synthetic, orc, seed):
         idx = torch.randint(0, n, (B, 12), dtype=torch.int32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed))
         ce = torch.empty(B, dtype=torch.int32, device="cuda")
         ch = torch.empty(B, dtype=torch.int32, device="cuda")
-        ops.eh_best(corr, corr32, idx, thr, 3 * thr, xmax, scratch=(ce, ch))
+        ws = ops.eh_best_workspace(B)
+        for _ in range(3 if B * n < 5e11 else 1):
+            ops.eh_best_native(corr, corr32, idx, thr, 3 * thr, xmax, workspace=ws)
         torch.cuda.synchronize()
-        reps = 3 if B * n < 5e11 else 1
+        reps = 5 if B * n < 5e11 else 1
         t0 = time.perf_counter()
         for _ in range(reps):
-            wE, wH, st = ops.eh_best(corr, corr32, idx, thr, 3 * thr, xmax, scratch=(ce, ch))
+            wE, wH, st = ops.eh_best_native(corr, corr32, idx, thr, 3 * thr, xmax, workspace=ws)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         rows.append({"matches": n, "hypotheses": B, "ms_per_step": dt * 1e3, "evals_per_s": 2.0 * n * B / dt,
                      "tflops_algorithmic": 57.0 * n * B / dt / 1e12, "winner_E": list(wE), "winner_H": list(wH), **st})
-        del idx, ce, ch
+        del idx, ce, ch, ws
     return rows
 
 
@@ -259,10 +261,11 @@ def main():
     best = torch.zeros(2, dtype=torch.int64, device="cuda")
     base = rank * B
     last_stats = {}
+    workspace = ops.eh_best_workspace(B)
 
     def step():
-        # tier 1: float32 upper bounds for all hypotheses; tier 2: float64 re-score of the candidates
-        (cE, iE), (cH, iH), st = ops.eh_best(corr, corr32, idx, thr, 3 * thr, xmax, scratch=(ce, ch))
+        # one library call: float32 bounds for all hypotheses -> candidates -> float64 re-score -> exact winners
+        (cE, iE), (cH, iH), st = ops.eh_best_native(corr, corr32, idx, thr, 3 * thr, xmax, workspace=workspace)
         last_stats.update(st)
         best.copy_(torch.tensor([sharding.pack_key(cE, base + iE), sharding.pack_key(cH, base + iH)], dtype=torch.int64))
         sharding.merge_best(best)  # RCCL all-reduce(max) of the packed winners when world > 1

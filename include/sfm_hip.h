@@ -61,6 +61,23 @@ int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const i
                      double thr_h, double xmax, double safety, int32_t one_sided, int32_t* up_e, int32_t* up_h,
                      void* stream);
 
+/* The whole arg-max step as one call: the exact winners of a block of hypotheses, i.e. the first
+ * maximum of the counts sfm_eh_score_f64 would return (largest count, lowest id), for E and for H.
+ * Internally a cascade of upper bounds: float32 bounds for all hypotheses (loose != 0: the cheaper
+ * one-sided/box forms) -> exact count of the hypothesis with the largest bound -> candidates whose
+ * bound reaches it -> tight float32 bounds when there are many -> float64 for the rest.  Replaces
+ * the best-so-far bookkeeping of src/ransac_algorithm.py:102-106 and :121-125 over nb iterations
+ * when only the final winner is wanted.
+ * workspace: device scratch of at least sfm_eh_best_workspace_bytes(nb) bytes (nothing is
+ * allocated on the device here).  result (HOST, int64[8]): count_e, index_e, count_h, index_h,
+ * candidates_e, candidates_h, re-bounded candidates, hypotheses scored in float64.
+ * Unlike the other entry points this one synchronises `stream` (it reads a few words back to decide
+ * the next level). */
+int64_t sfm_eh_best_workspace_bytes(int64_t nb);
+int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
+                double xmax, double safety, int32_t loose, void* workspace, int64_t workspace_bytes, int64_t* result,
+                void* stream);
+
 /* The models themselves: F_out (estimate_F_DLT, :216-263, before the singular values are
  * replaced), E_out (after enforce_essential, :176-190) and H_out (estimate_H_DLT, :266-293),
  * each double[nb][9] or NULL.  Same solvers as sfm_eh_score_f64. */

@@ -611,7 +611,72 @@ __global__ __launch_bounds__(kBlock) void argmax_kernel(const int* __restrict__ 
     const unsigned long long o = __shfl_xor(key, s, 64);
     key = o > key ? o : key;
   }
-  if ((threadIdx.x & 63) == 0 && key) atomicMax(best + cam, key);
+  __shared__ unsigned long long wave_key[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) wave_key[threadIdx.x >> 6] = key;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) key = wave_key[w] > key ? wave_key[w] : key;
+    if (key) atomicMax(best + cam, key);  // one atomic per workgroup
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Helpers of the bound cascade (sfm_eh_best): all tiny, all device-resident bookkeeping.
+// ---------------------------------------------------------------------------------------
+struct BestInfo {  // mirrored on the host, 8 x int64
+  long long lead_e, lead_h, floor_e, floor_h, ncand_e, ncand_h, pad0, pad1;
+};
+
+// copies the index rows of the two hypotheses with the largest bounds into rows[2][12]
+__global__ void gather_leaders_kernel(const unsigned long long* __restrict__ keys, const int32_t* __restrict__ idx, long long nb,
+                                      int32_t* __restrict__ rows, BestInfo* __restrict__ info) {
+  const int t = threadIdx.x;
+  if (t < 24) {
+    const int which = t / 12;
+    long long id = (long long)(0xFFFFFFFFull - (keys[which] & 0xFFFFFFFFull));
+    if (keys[which] == 0 || id >= nb) id = 0;
+    rows[t] = idx[12 * id + (t % 12)];
+    if (t % 12 == 0) {
+      if (which == 0) info->lead_e = id; else info->lead_h = id;
+    }
+  }
+}
+
+// floors = exact counts of the leaders; counts the hypotheses whose bound reaches the floor and
+// appends their ids (unordered) to cand_e / cand_h while they fit into `cap` entries each
+__global__ __launch_bounds__(kBlock) void select_candidates_kernel(const int* __restrict__ up_e, const int* __restrict__ up_h, long long nb,
+                                                                   const int* __restrict__ lead_counts /* ce[2] ch[2] */,
+                                                                   BestInfo* __restrict__ info, int32_t* __restrict__ cand_e,
+                                                                   int32_t* __restrict__ cand_h, int cap) {
+  const int fe = lead_counts[0], fh = lead_counts[3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    info->floor_e = fe;
+    info->floor_h = fh;
+  }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += (long long)gridDim.x * blockDim.x) {
+    if (up_e[i] >= fe) {
+      const unsigned long long slot = atomicAdd((unsigned long long*)&info->ncand_e, 1ull);
+      if (slot < (unsigned long long)cap) cand_e[slot] = (int32_t)i;
+    }
+    if (up_h[i] >= fh) {
+      const unsigned long long slot = atomicAdd((unsigned long long*)&info->ncand_h, 1ull);
+      if (slot < (unsigned long long)cap) cand_h[slot] = (int32_t)i;
+    }
+  }
+}
+
+// rows_out[k][12] = idx[ids[k]][12]
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const int32_t* __restrict__ ids, int count, const int32_t* __restrict__ idx,
+                                                             int32_t* __restrict__ rows_out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 12LL * count) rows_out[t] = idx[12LL * ids[t / 12] + (t % 12)];
+}
+
+// keeps the candidates whose tight bound still reaches the floor (in place, unordered)
+__global__ __launch_bounds__(kBlock) void refilter_kernel(const int32_t* __restrict__ ids_in, const int* __restrict__ bound, int count, int floor,
+                                                          int32_t* __restrict__ ids_out, unsigned long long* __restrict__ n_out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count && bound[t] >= floor) ids_out[atomicAdd(n_out, 1ull)] = ids_in[t];
 }
 
 __global__ void t_winner_kernel(const double* __restrict__ pts_all, CamOffsets offs, const int32_t* __restrict__ idx, long long nb,
@@ -800,12 +865,10 @@ const char* sfm_hip_error_string(int code) {
 
 int sfm_hip_abi_version(void) { return 1; }
 
-int sfm_eh_score_f64(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, int32_t* count_e,
-                     int32_t* count_h, void* stream) {
-  clear_stale_error();
+static int launch_eh_score(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, int32_t* count_e,
+                           int32_t* count_h, hipStream_t st) {
   if (!corr || !idx || !count_e || !count_h || n <= 0 || nb < 0) return SFM_EINVAL;
   if (nb == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
   const long long tiles = (nb + kBlock - 1) / kBlock;
   if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
   const int splits = choose_splits(tiles, n);
@@ -821,6 +884,12 @@ int sfm_eh_score_f64(const double* corr, int32_t n, const int32_t* idx, int64_t 
   return check_launch();
 }
 
+int sfm_eh_score_f64(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, int32_t* count_e,
+                     int32_t* count_h, void* stream) {
+  clear_stale_error();
+  return launch_eh_score(corr, n, idx, nb, thr_e, thr_h, count_e, count_h, (hipStream_t)stream);
+}
+
 int sfm_corr_to_f32(const double* corr, int32_t n, float* corr32, void* stream) {
   clear_stale_error();
   if (!corr || !corr32 || n < 0) return SFM_EINVAL;
@@ -829,13 +898,11 @@ int sfm_corr_to_f32(const double* corr, int32_t n, float* corr32, void* stream) 
   return check_launch();
 }
 
-int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
-                     double xmax, double safety, int32_t one_sided, int32_t* up_e, int32_t* up_h, void* stream) {
-  clear_stale_error();
+static int launch_eh_upper(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
+                           double xmax, double safety, int32_t one_sided, int32_t* up_e, int32_t* up_h, hipStream_t st) {
   if (!corr || !corr32 || !idx || !up_e || !up_h || n <= 0 || nb < 0) return SFM_EINVAL;
   if (!(xmax > 0.0 && xmax < 1.0e6 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
   if (nb == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
   const long long tiles = (nb + kBlock - 1) / kBlock;
   if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
   const int splits = choose_splits(tiles, n);
@@ -861,6 +928,170 @@ int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const i
     eh_upper_kernel<false><<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, (const float4*)corr32, n, idx, nb, ke, kh, xmax,
                                                                              safety, up_e, up_h, pps, splits > 1);
   return check_launch();
+}
+
+int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
+                     double xmax, double safety, int32_t one_sided, int32_t* up_e, int32_t* up_h, void* stream) {
+  clear_stale_error();
+  return launch_eh_upper(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, one_sided, up_e, up_h, (hipStream_t)stream);
+}
+
+// ---- the whole bound cascade as one call -------------------------------------------------
+namespace {
+constexpr int kCandCap = 65536;      // candidates kept per class; more than that -> score everything in float64
+constexpr int kTightenAbove = 4096;  // more candidates than this are first re-bounded with the tight float32 tests
+
+struct BestWs {
+  int *up_e, *up_h, *lead_counts, *sc_e, *sc_h;
+  unsigned long long *keys, *n2;
+  BestInfo* info;
+  int32_t *lead_rows, *cand_e, *cand_h, *cand2, *rows;
+};
+
+inline size_t carve(char* base, int64_t nb, BestWs* w) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += (bytes + 255) & ~(size_t)255;
+    return p;
+  };
+  w->up_e = (int*)take(sizeof(int) * nb);
+  w->up_h = (int*)take(sizeof(int) * nb);
+  w->keys = (unsigned long long*)take(sizeof(unsigned long long) * 2);
+  w->n2 = (unsigned long long*)take(sizeof(unsigned long long) * 2);
+  w->info = (BestInfo*)take(sizeof(BestInfo));
+  w->lead_rows = (int32_t*)take(sizeof(int32_t) * 24);
+  w->lead_counts = (int*)take(sizeof(int) * 4);
+  w->cand_e = (int32_t*)take(sizeof(int32_t) * kCandCap);
+  w->cand_h = (int32_t*)take(sizeof(int32_t) * kCandCap);
+  w->cand2 = (int32_t*)take(sizeof(int32_t) * 2 * kCandCap);
+  w->rows = (int32_t*)take(sizeof(int32_t) * 12 * 2 * kCandCap);
+  w->sc_e = (int*)take(sizeof(int) * 2 * kCandCap);
+  w->sc_h = (int*)take(sizeof(int) * 2 * kCandCap);
+  return off;
+}
+}  // namespace
+
+int64_t sfm_eh_best_workspace_bytes(int64_t nb) {
+  BestWs w;
+  return nb < 0 ? -1 : (int64_t)carve(nullptr, nb, &w);
+}
+
+#define SFM_TRY(expr)            \
+  do {                           \
+    int rc_ = (int)(expr);       \
+    if (rc_ != 0) return rc_;    \
+  } while (0)
+
+int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax,
+                double safety, int32_t loose, void* workspace, int64_t workspace_bytes, int64_t* result, void* stream) {
+  clear_stale_error();
+  if (!corr || !corr32 || !idx || !workspace || !result || n <= 0 || nb <= 0 || (uint64_t)nb > 0x7FFFFFFFull) return SFM_EINVAL;
+  BestWs w;
+  if ((int64_t)carve((char*)workspace, nb, &w) > workspace_bytes) return SFM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < 8; ++i) result[i] = 0;
+  // level 1: float32 bounds for every hypothesis, leaders, their exact counts, candidate lists
+  SFM_TRY(launch_eh_upper(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, loose, w.up_e, w.up_h, st));
+  SFM_TRY(hipMemsetAsync(w.keys, 0, 256 * 3, st));  // keys, n2, info (three consecutive 256-byte slots)
+  {
+    const long long tiles = (nb + kBlock - 1) / kBlock;
+    const int ablocks = (int)(tiles < 256 ? tiles : 256);
+    argmax_kernel<<<dim3(ablocks, 1), kBlock, 0, st>>>(w.up_e, nb, 0ull, w.keys);
+    argmax_kernel<<<dim3(ablocks, 1), kBlock, 0, st>>>(w.up_h, nb, 0ull, w.keys + 1);
+    gather_leaders_kernel<<<1, 64, 0, st>>>(w.keys, idx, nb, w.lead_rows, w.info);
+    SFM_TRY(check_launch());
+    SFM_TRY(launch_eh_score(corr, n, w.lead_rows, 2, thr_e, thr_h, w.lead_counts, w.lead_counts + 2, st));
+    select_candidates_kernel<<<ablocks, kBlock, 0, st>>>(w.up_e, w.up_h, nb, w.lead_counts, w.info, w.cand_e, w.cand_h, kCandCap);
+    SFM_TRY(check_launch());
+  }
+  BestInfo info;
+  SFM_TRY(hipMemcpyAsync(&info, w.info, sizeof(info), hipMemcpyDeviceToHost, st));
+  SFM_TRY(hipStreamSynchronize(st));
+  result[0] = info.floor_e;
+  result[1] = info.lead_e;
+  result[2] = info.floor_h;
+  result[3] = info.lead_h;
+  result[4] = info.ncand_e;
+  result[5] = info.ncand_h;
+  if (info.ncand_e <= 1 && info.ncand_h <= 1) return 0;  // each leader is the only hypothesis that can reach its own count
+  if (info.ncand_e > kCandCap || info.ncand_h > kCandCap) {
+    // (near-)universal ties: no bound can help, score everything exactly
+    SFM_TRY(launch_eh_score(corr, n, idx, nb, thr_e, thr_h, w.up_e, w.up_h, st));
+    SFM_TRY(hipMemsetAsync(w.keys, 0, 256, st));
+    const long long tiles = (nb + kBlock - 1) / kBlock;
+    const int ablocks = (int)(tiles < 256 ? tiles : 256);
+    argmax_kernel<<<dim3(ablocks, 1), kBlock, 0, st>>>(w.up_e, nb, 0ull, w.keys);
+    argmax_kernel<<<dim3(ablocks, 1), kBlock, 0, st>>>(w.up_h, nb, 0ull, w.keys + 1);
+    SFM_TRY(check_launch());
+    unsigned long long keys[2];
+    SFM_TRY(hipMemcpyAsync(keys, w.keys, sizeof(keys), hipMemcpyDeviceToHost, st));
+    SFM_TRY(hipStreamSynchronize(st));
+    for (int k = 0; k < 2; ++k) {
+      result[2 * k] = (int64_t)(keys[k] >> 32);
+      result[2 * k + 1] = (int64_t)(0xFFFFFFFFull - (keys[k] & 0xFFFFFFFFull));
+    }
+    result[7] = nb;
+    return 0;
+  }
+  int ne = (int)info.ncand_e, nh = (int)info.ncand_h;
+  int32_t* list_e = w.cand_e;
+  int32_t* list_h = w.cand_h;
+  if (loose && ne + nh > kTightenAbove) {
+    // level 2: tight float32 bounds on the candidates only
+    gather_rows_kernel<<<div_up(12LL * ne, kBlock), kBlock, 0, st>>>(w.cand_e, ne, idx, w.rows);
+    gather_rows_kernel<<<div_up(12LL * nh, kBlock), kBlock, 0, st>>>(w.cand_h, nh, idx, w.rows + 12LL * ne);
+    SFM_TRY(check_launch());
+    SFM_TRY(launch_eh_upper(corr, corr32, n, w.rows, ne + nh, thr_e, thr_h, xmax, safety, 0, w.sc_e, w.sc_h, st));
+    SFM_TRY(hipMemsetAsync(w.n2, 0, 2 * sizeof(unsigned long long), st));
+    refilter_kernel<<<div_up(ne, kBlock), kBlock, 0, st>>>(w.cand_e, w.sc_e, ne, (int)info.floor_e, w.cand2, w.n2);
+    refilter_kernel<<<div_up(nh, kBlock), kBlock, 0, st>>>(w.cand_h, w.sc_h + ne, nh, (int)info.floor_h, w.cand2 + kCandCap, w.n2 + 1);
+    SFM_TRY(check_launch());
+    unsigned long long n2[2];
+    SFM_TRY(hipMemcpyAsync(n2, w.n2, sizeof(n2), hipMemcpyDeviceToHost, st));
+    SFM_TRY(hipStreamSynchronize(st));
+    result[6] = ne + nh;
+    ne = (int)n2[0];
+    nh = (int)n2[1];
+    list_e = w.cand2;
+    list_h = w.cand2 + kCandCap;
+  }
+  // level 3: exact float64 counts of what is left; first maximum = largest count, lowest id
+  gather_rows_kernel<<<div_up(12LL * ne, kBlock), kBlock, 0, st>>>(list_e, ne, idx, w.rows);
+  gather_rows_kernel<<<div_up(12LL * nh, kBlock), kBlock, 0, st>>>(list_h, nh, idx, w.rows + 12LL * ne);
+  SFM_TRY(check_launch());
+  SFM_TRY(launch_eh_score(corr, n, w.rows, ne + nh, thr_e, thr_h, w.sc_e, w.sc_h, st));
+  static thread_local int32_t* host_buf = nullptr;
+  static thread_local size_t host_cap = 0;
+  const size_t need = (size_t)(ne + nh) * 2;
+  if (host_cap < need) {
+    free(host_buf);
+    host_buf = (int32_t*)malloc(sizeof(int32_t) * need);
+    host_cap = host_buf ? need : 0;
+    if (!host_buf) return SFM_EINVAL;
+  }
+  int32_t* ids = host_buf;
+  int32_t* cnt = host_buf + (ne + nh);
+  SFM_TRY(hipMemcpyAsync(ids, list_e, sizeof(int32_t) * ne, hipMemcpyDeviceToHost, st));
+  SFM_TRY(hipMemcpyAsync(ids + ne, list_h, sizeof(int32_t) * nh, hipMemcpyDeviceToHost, st));
+  SFM_TRY(hipMemcpyAsync(cnt, w.sc_e, sizeof(int32_t) * ne, hipMemcpyDeviceToHost, st));
+  SFM_TRY(hipMemcpyAsync(cnt + ne, w.sc_h + ne, sizeof(int32_t) * nh, hipMemcpyDeviceToHost, st));
+  SFM_TRY(hipStreamSynchronize(st));
+  for (int cls = 0; cls < 2; ++cls) {
+    const int lo = cls ? ne : 0, hi = cls ? ne + nh : ne;
+    long long bc = -1, bi = -1;
+    for (int k = lo; k < hi; ++k)
+      if (cnt[k] > bc || (cnt[k] == bc && ids[k] < bi)) {
+        bc = cnt[k];
+        bi = ids[k];
+      }
+    if (bi >= 0) {
+      result[2 * cls] = bc;
+      result[2 * cls + 1] = bi;
+    }
+  }
+  result[7] = ne + nh;
+  return 0;
 }
 
 int sfm_eh_models_f64(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double* F_out, double* E_out, double* H_out,

@@ -76,6 +76,26 @@ def eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, out=None, one_si
     return ue, uh
 
 
+def eh_best_workspace(nb):
+    """Device scratch for eh_best_native (uint8 tensor)."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    return _empty((int(lib.sfm_eh_best_workspace_bytes(int(nb))),), torch.uint8)
+
+
+def eh_best_native(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, loose=True, workspace=None):
+    """The bound cascade as ONE library call (sfm_eh_best).  Same result as eh_best below."""
+    lib = C.load_library()
+    nb = idx.shape[0]
+    if workspace is None:
+        workspace = eh_best_workspace(nb)
+    res = np.zeros(8, np.int64)
+    C.check(lib.sfm_eh_best(C.dptr(corr), C.dptr(corr32), corr.shape[0], C.dptr(idx), nb, float(thr_e), float(thr_h), float(xmax), float(safety),
+                            int(bool(loose)), C.dptr(workspace), workspace.numel(), C.hptr(res), C.stream_ptr()))
+    stats = {"candidates_e": int(res[4]), "candidates_h": int(res[5]), "tightened": int(res[6]), "rescored_f64": int(res[7])}
+    return (int(res[0]), int(res[1])), (int(res[2]), int(res[3])), stats
+
+
 TIGHTEN_ABOVE = 4096  # candidates beyond this count go through the tight float32 bound before float64
 
 

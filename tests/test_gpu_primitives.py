@@ -278,3 +278,38 @@ def test_loose_bound_cascade_is_exact(ops, dev, inl, pl, n, B, seed, monkeypatch
         (cE, iE), (cH, iH), stats = ops.eh_best(corr, c32, idx, thr, 3 * thr, xmax, loose=loose)
         assert (cE, iE) == (int(ce.max()), int(np.argmax(ce))), stats
         assert (cH, iH) == (int(ch.max()), int(np.argmax(ch))), stats
+
+
+@pytest.mark.parametrize("inl,pl,n,B,seed,loose", [(0.3, 0.5, 5000, 100000, 0, True), (0.3, 0.5, 5000, 100000, 0, False),
+                                                   (0.0, 0.5, 3000, 200000, 6, True), (0.05, 0.5, 777, 70001, 3, True)])
+def test_native_cascade_entry_point(ops, dev, inl, pl, n, B, seed, loose):
+    """sfm_eh_best (the whole cascade inside the library, caller-provided workspace) returns the
+    first maximum of the float64 counts, also when thousands of candidates go through the tight
+    re-bounding level (pure-outlier scene) and for sizes that are not multiples of anything."""
+    sc, x1, x2 = scene(n=n, inl=inl, pl=pl, seed=seed)
+    corr_h = ops.pack_corr(x1, x2)
+    corr = dev(corr_h)
+    c32 = ops.corr_to_f32(corr)
+    xmax = float(np.abs(corr_h).max())
+    idx = dev(np.random.default_rng(seed).integers(0, n, size=(B, 12)), np.int32)
+    thr = 1.0 / sc["K"][0][0]
+    ce, ch = [t.cpu().numpy() for t in ops.eh_score(corr, idx, thr, 3 * thr)]
+    ws = ops.eh_best_workspace(B)
+    for _ in range(2):  # the workspace is reused: stale contents must not matter
+        (cE, iE), (cH, iH), stats = ops.eh_best_native(corr, c32, idx, thr, 3 * thr, xmax, loose=loose, workspace=ws)
+        assert (cE, iE) == (int(ce.max()), int(np.argmax(ce))), stats
+        assert (cH, iH) == (int(ch.max()), int(np.argmax(ch))), stats
+    if inl == 0.0:
+        assert stats["tightened"] > 4096  # the middle level really ran
+
+
+def test_native_cascade_universal_ties_fall_back_to_float64(ops, dev):
+    """Identical matches: every hypothesis has the same count, more candidates than the lists hold."""
+    n, B = 200, 100000
+    corr_h = np.tile(np.array([[0.1, -0.2, 0.12, -0.18]]), (n, 1))
+    corr = dev(corr_h)
+    idx = dev(np.random.default_rng(0).integers(0, n, size=(B, 12)), np.int32)
+    ce, ch = [t.cpu().numpy() for t in ops.eh_score(corr, idx, 4e-4, 1.2e-3)]
+    (cE, iE), (cH, iH), stats = ops.eh_best_native(corr, ops.corr_to_f32(corr), idx, 4e-4, 1.2e-3, 0.2)
+    assert (cE, iE) == (int(ce.max()), int(np.argmax(ce))), stats
+    assert (cH, iH) == (int(ch.max()), int(np.argmax(ch))), stats
