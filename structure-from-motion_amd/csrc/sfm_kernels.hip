@@ -1015,6 +1015,20 @@ int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_
   result[4] = info.ncand_e;
   result[5] = info.ncand_h;
   if (info.ncand_e <= 1 && info.ncand_h <= 1) return 0;  // each leader is the only hypothesis that can reach its own count
+  if (loose && (info.ncand_e > kCandCap || info.ncand_h > kCandCap)) {
+    // too many survivors of the loose bounds for the candidate lists (e.g. a scene whose best count is
+    // tiny): apply the tight bounds to every hypothesis and select again with the same floors
+    SFM_TRY(launch_eh_upper(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, 0, w.up_e, w.up_h, st));
+    const long long tiles = (nb + kBlock - 1) / kBlock;
+    const int ablocks = (int)(tiles < 256 ? tiles : 256);
+    SFM_TRY(hipMemsetAsync(&w.info->ncand_e, 0, 2 * sizeof(long long), st));
+    select_candidates_kernel<<<ablocks, kBlock, 0, st>>>(w.up_e, w.up_h, nb, w.lead_counts, w.info, w.cand_e, w.cand_h, kCandCap);
+    SFM_TRY(check_launch());
+    SFM_TRY(hipMemcpyAsync(&info, w.info, sizeof(info), hipMemcpyDeviceToHost, st));
+    SFM_TRY(hipStreamSynchronize(st));
+    result[6] = nb;
+    loose = 0;  // the lists now hold survivors of the tight bounds
+  }
   if (info.ncand_e > kCandCap || info.ncand_h > kCandCap) {
     // (near-)universal ties: no bound can help, score everything exactly
     SFM_TRY(launch_eh_score(corr, n, idx, nb, thr_e, thr_h, w.up_e, w.up_h, st));

@@ -313,3 +313,19 @@ def test_native_cascade_universal_ties_fall_back_to_float64(ops, dev):
     (cE, iE), (cH, iH), stats = ops.eh_best_native(corr, ops.corr_to_f32(corr), idx, 4e-4, 1.2e-3, 0.2)
     assert (cE, iE) == (int(ce.max()), int(np.argmax(ce))), stats
     assert (cH, iH) == (int(ch.max()), int(np.argmax(ch))), stats
+
+
+def test_native_cascade_many_loose_survivors(ops, dev):
+    """A scene whose best counts are tiny: more hypotheses survive the loose bounds than the
+    candidate lists hold, so the tight bounds are applied to everything before the float64 level."""
+    n, B = 3000, 400000
+    sc, x1, x2 = scene(n=n, inl=0.0, pl=0.5, seed=8)
+    corr_h = ops.pack_corr(x1, x2)
+    corr = dev(corr_h)
+    idx = dev(np.random.default_rng(8).integers(0, n, size=(B, 12)), np.int32)
+    thr = 1.0 / sc["K"][0][0]
+    ce, ch = [t.cpu().numpy() for t in ops.eh_score(corr, idx, thr, 3 * thr)]
+    (cE, iE), (cH, iH), stats = ops.eh_best_native(corr, ops.corr_to_f32(corr), idx, thr, 3 * thr, float(np.abs(corr_h).max()))
+    assert (cE, iE) == (int(ce.max()), int(np.argmax(ce))), stats
+    assert (cH, iH) == (int(ch.max()), int(np.argmax(ch))), stats
+    assert stats["candidates_e"] > 65536 and stats["tightened"] == B and stats["rescored_f64"] < B, stats
