@@ -33,17 +33,17 @@ PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector FP64 (half of the FP32 vector rate
 PMC_TRAFFIC_BYTES = (2 * 26104.6 + 7812.5) * 1024  # FETCH_SIZE x2 + WRITE_SIZE of the dominant kernel, KB -> bytes
 
 
-def cpu_baseline(x1n, x2n, thr, n_matches, sample_hyps, seed):
-    """The NumPy oracle (a port of the reference loop body) on a bounded sample of the same
-    workload, one host thread."""
+def cpu_baseline(x1n, x2n, thr, n_matches, idx):
+    """The NumPy oracle (a port of the reference loop body) on a bounded sample (the head of this
+    rank's index sets) of the same workload, one host thread."""
     from oracle import sfm_oracle as orc
 
     try:
         from threadpoolctl import threadpool_limits
     except Exception:  # pragma: no cover
         threadpool_limits = None
-    np.random.seed(seed)
-    idx = np.random.randint(0, n_matches, size=12 * sample_hyps).reshape(sample_hyps, 12)
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    sample_hyps = idx.shape[0]
     t0 = time.perf_counter()
     if threadpool_limits is not None:
         with threadpool_limits(limits=1):
@@ -152,7 +152,7 @@ def sweep(torch, ops, _capi, synthetic, orc, seed):
         corr = _capi.dev(corr_h)
         corr32 = ops.corr_to_f32(corr)
         xmax = float(np.abs(corr_h).max())
-        idx = torch.randint(0, n, (B, 12), dtype=torch.int32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed))
+        idx = ops.index_sets(seed, 0, B, n)  # generated on the device from (seed, hypothesis id)
         ce = torch.empty(B, dtype=torch.int32, device="cuda")
         ch = torch.empty(B, dtype=torch.int32, device="cuda")
         ws = ops.eh_best_workspace(B)
@@ -213,6 +213,9 @@ def main():
     ap.add_argument("--hyps", type=int, default=1000000, help="hypotheses per GPU")
     ap.add_argument("--cpu-sample", type=int, default=50000, help="hypotheses of the CPU baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--index-source", choices=["auto", "legacy", "philox"], default="auto",
+                    help="legacy: np.random.randint on the host, as the reference draws its samples; philox: generated on the device "
+                    "from (seed, global hypothesis id), identical under any sharding; auto = legacy on one GPU, philox on several")
     ap.add_argument("--no-secondary", action="store_true", help="skip the T-RANSAC / LM / triangulation timings")
     ap.add_argument("--e2e", action="store_true", help="only run the synthetic dataset-5-shaped end-to-end geometry and print it")
     ap.add_argument("--e2e-cpu", action="store_true", help="with --e2e: also time the NumPy oracle end to end (minutes) and compare")
@@ -250,16 +253,21 @@ def main():
     x1n = orc.normalize_K(sc["K"], sc["x1"])
     x2n = orc.normalize_K(sc["K"], sc["x2"])
     corr = _capi.dev(ops.pack_corr(x1n, x2n))
-    # global hypothesis ids [rank*B, (rank+1)*B): index sets come from one legacy stream per rank
-    np.random.seed(args.seed + 1000 * rank)
-    idx_host = np.random.randint(0, n, size=12 * B).reshape(B, 12).astype(np.int32)
-    idx = _capi.dev(idx_host)
+    # this rank scores the global hypothesis ids [rank*B, (rank+1)*B)
+    base = rank * B
+    index_source = args.index_source if args.index_source != "auto" else ("legacy" if world == 1 else "philox")
+    if index_source == "legacy":
+        np.random.seed(args.seed + 1000 * rank)
+        idx_host = np.random.randint(0, n, size=12 * B).reshape(B, 12).astype(np.int32)
+        idx = _capi.dev(idx_host)
+    else:
+        idx = ops.index_sets(args.seed, base, B, n)
+        idx_host = idx.cpu().numpy()
     corr32 = ops.corr_to_f32(corr)
     xmax = float(np.abs(np.concatenate([x1n[:2], x2n[:2]])).max())
     ce = torch.empty(B, dtype=torch.int32, device="cuda")
     ch = torch.empty(B, dtype=torch.int32, device="cuda")
     best = torch.zeros(2, dtype=torch.int64, device="cuda")
-    base = rank * B
     last_stats = {}
     workspace = ops.eh_best_workspace(B)
 
@@ -339,6 +347,8 @@ def main():
                 "winners merged by all-reduce(max)",
                 "matches": n,
                 "hypotheses_per_gpu": B,
+                "index_sets": "np.random.randint on the host (legacy stream)" if index_source == "legacy"
+                else "Philox4x32-10 on the device, keyed by (seed, global hypothesis id)",
                 "pixel_threshold": 1.0,
                 "winner_E": {"count": int(cnt[0]), "index": int(ind[0])},
                 "winner_H": {"count": int(cnt[1]), "index": int(ind[1])},
@@ -372,7 +382,7 @@ def main():
             },
         }
         if args.cpu_sample > 0 and world == 1:
-            base_res, idx_s, cE_s, cH_s = cpu_baseline(x1n, x2n, thr, n, args.cpu_sample, args.seed + 1000 * rank)
+            base_res, idx_s, cE_s, cH_s = cpu_baseline(x1n, x2n, thr, n, idx_host[: args.cpu_sample])
             out["cpu_baseline"] = base_res
             # the CPU sample is the head of this rank's index stream: reuse it as a parity check
             ok = np.array([len(set(r[:8])) == 8 and len(set(r[8:])) == 4 for r in idx_s])

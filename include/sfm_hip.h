@@ -178,6 +178,16 @@ int sfm_t_models_f64(const double* pts, int32_t m, const int32_t* idx, int64_t n
 int sfm_lm_translation_f64(const double* K, const double* pts, const int64_t* cam_off, int32_t ncam, const double* T0,
                            int32_t iters, double mu, double* work, double* T_out, double* history, void* stream);
 
+/* Index sets of a hypothesis range generated on the device with a counter-based generator:
+ * the counterpart of the sample draws `np.random.randint(0, N, size=8)` / `size=4`
+ * (src/ransac_algorithm.py:92,116) and `size=2` (src/estimate_translation.py:65) for runs that
+ * shard a hypothesis range over several GPUs: word w of hypothesis id is
+ * Philox4x32-10(counter=(id_lo, id_hi, w/4, 0), key=(seed_lo, seed_hi))[w%4] and the index is
+ * (word * n) >> 32, so any split of [first_id, first_id + nb) yields the same sets.
+ * width: 12 (E/H, idx int32[nb][12], 16-byte aligned) or 2 (translation, idx int32[nb][2]).
+ * (Runs that must follow the reference's seeded global np.random stream draw on the host.) */
+int sfm_index_sets_i32(uint64_t seed, uint64_t first_id, int64_t nb, int32_t n, int32_t width, int32_t* idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

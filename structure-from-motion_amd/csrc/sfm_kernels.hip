@@ -41,6 +41,26 @@ __device__ __forceinline__ void gather_samples(const double4* __restrict__ corr,
   }
 }
 
+// Index sets generated on the device from (seed, global hypothesis id): width 12 for the E/H
+// stage (8 + 4 matches), width 2 for the translation stage.
+template <int kWidth>
+__global__ __launch_bounds__(kBlock) void index_sets_kernel(unsigned long long seed, unsigned long long first_id, long long nb, unsigned n,
+                                                            int32_t* __restrict__ idx) {
+  const long long b = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (b >= nb) return;
+  int32_t row[kWidth];
+  philox_index_row<kWidth>(seed, first_id + (unsigned long long)b, n, row);
+  if constexpr (kWidth % 4 == 0) {
+    int4* dst = reinterpret_cast<int4*>(idx + b * kWidth);
+#pragma unroll
+    for (int j = 0; j < kWidth / 4; ++j) dst[j] = make_int4(row[4 * j], row[4 * j + 1], row[4 * j + 2], row[4 * j + 3]);
+  } else {
+    int2* dst = reinterpret_cast<int2*>(idx + b * kWidth);
+#pragma unroll
+    for (int j = 0; j < kWidth / 2; ++j) dst[j] = make_int2(row[2 * j], row[2 * j + 1]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // E/H hypothesis scoring.  grid = (hypothesis tiles, point splits).
 // ---------------------------------------------------------------------------------------
@@ -1333,6 +1353,21 @@ int sfm_lm_translation_f64(const double* K, const double* pts, const int64_t* ca
   int rc = fill_offsets(cam_off, ncam, &offs);
   if (rc) return rc;
   lm_kernel<<<ncam, kLmBlock, 0, (hipStream_t)stream>>>(K, pts, offs, T0, iters, mu, work, T_out, history);
+  return check_launch();
+}
+
+int sfm_index_sets_i32(uint64_t seed, uint64_t first_id, int64_t nb, int32_t n, int32_t width, int32_t* idx, void* stream) {
+  clear_stale_error();
+  if (nb < 0 || n <= 0 || (width != 12 && width != 2)) return SFM_EINVAL;
+  if (nb == 0) return 0;
+  if (!idx || ((uintptr_t)idx & (width == 12 ? 15u : 7u)) != 0) return SFM_EINVAL;
+  const long long tiles = (nb + kBlock - 1) / kBlock;
+  if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (width == 12)
+    index_sets_kernel<12><<<(unsigned)tiles, kBlock, 0, st>>>(seed, first_id, nb, (unsigned)n, idx);
+  else
+    index_sets_kernel<2><<<(unsigned)tiles, kBlock, 0, st>>>(seed, first_id, nb, (unsigned)n, idx);
   return check_launch();
 }
 

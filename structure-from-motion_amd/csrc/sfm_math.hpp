@@ -15,6 +15,7 @@
 // Host build of the same numerics.  Only the unit-test harness under tests/ compiles this
 // branch (to debug the small-matrix code without a GPU); the shipped library is device code.
 #include <cmath>
+#include <cstdint>
 #define SFM_FN inline
 #define SFM_WAVE_ALL(x) (x)
 using std::copysign;
@@ -581,6 +582,43 @@ SFM_FN void homography_decompose(const T (&Hin)[9], bool flip, T (&R1)[3][3], T 
   for (int i = 0; i < 3; ++i) {
     t1[i] = fma(R1[i][0], ta[0], fma(R1[i][1], ta[1], R1[i][2] * ta[2]));
     t2[i] = fma(R2[i][0], tb[0], fma(R2[i][1], tb[1], R2[i][2] * tb[2]));
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Counter-based index sets: Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy
+// as 1, 2, 3", SC'11).  Word w of hypothesis `id` under `seed` is
+//   philox4x32_10(counter = (id_lo, id_hi, w / 4, 0), key = (seed_lo, seed_hi))[w % 4]
+// and the index is the high half of word * n, so the sets are a pure function of (seed, id, n)
+// and every sharding of an id range produces the same sets.
+// ---------------------------------------------------------------------------------------
+SFM_FN void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Fills row[0..width) with indices in [0, n) for hypothesis `id`.
+template <int kWidth>
+SFM_FN void philox_index_row(uint64_t seed, uint64_t id, uint32_t n, int32_t (&row)[kWidth]) {
+#pragma unroll
+  for (int blk = 0; blk < (kWidth + 3) / 4; ++blk) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)id, (uint32_t)(id >> 32), (uint32_t)blk, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * blk + j < kWidth) row[4 * blk + j] = (int32_t)(((uint64_t)w[j] * n) >> 32);
   }
 }
 

@@ -359,6 +359,19 @@ def decode_best(best_host):
     return count, index
 
 
+def index_sets(seed, first_id, nb, n, width=12, out=None):
+    """Device-generated index sets int32[nb][width] of the hypothesis ids [first_id, first_id + nb): a pure function
+    of (seed, id, n), so every sharding of an id range sees the same sets (the reference draws them from the global
+    np.random stream: src/ransac_algorithm.py:92,116, src/estimate_translation.py:65)."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    idx = out if out is not None else _empty((nb, width), torch.int32)
+    if tuple(idx.shape) != (nb, width) or idx.dtype != torch.int32 or not idx.is_contiguous():
+        raise ValueError("out must be a contiguous int32 [nb][width] device tensor")
+    C.check(lib.sfm_index_sets_i32(int(seed) & (2**64 - 1), int(first_id), nb, int(n), width, C.dptr(idx), C.stream_ptr()))
+    return idx
+
+
 def t_models(pts, idx):
     torch = C.torch_cuda()
     lib = C.load_library()

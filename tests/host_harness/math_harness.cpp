@@ -88,4 +88,24 @@ void h_score_t(const double* pts, int m, const double* T, int64_t nb, double thr
     cnt[b] = c;
   }
 }
+void h_index_sets(uint64_t seed, uint64_t first_id, int64_t nb, uint32_t n, int width, int32_t* idx) {
+  for (int64_t b = 0; b < nb; ++b) {
+    if (width == 12) {
+      int32_t row[12];
+      philox_index_row<12>(seed, first_id + (uint64_t)b, n, row);
+      for (int j = 0; j < 12; ++j) idx[12 * b + j] = row[j];
+    } else {
+      int32_t row[2];
+      philox_index_row<2>(seed, first_id + (uint64_t)b, n, row);
+      for (int j = 0; j < 2; ++j) idx[2 * b + j] = row[j];
+    }
+  }
 }
+
+void h_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+  uint32_t o[4];
+  philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], o);
+  for (int j = 0; j < 4; ++j) out[j] = o[j];
+}
+
+}  // extern "C"

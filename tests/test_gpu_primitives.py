@@ -329,3 +329,21 @@ def test_native_cascade_many_loose_survivors(ops, dev):
     assert (cE, iE) == (int(ce.max()), int(np.argmax(ce))), stats
     assert (cH, iH) == (int(ch.max()), int(np.argmax(ch))), stats
     assert stats["candidates_e"] > 65536 and stats["tightened"] == B and stats["rescored_f64"] < B, stats
+
+
+def test_device_index_sets_match_oracle_and_are_sharding_invariant(ops):
+    """sfm_index_sets_i32 against the NumPy Philox restatement, and: any split of an id range gives the same sets."""
+    import torch
+
+    from oracle import philox
+
+    for seed, first, nb, n, width in [(0, 0, 100000, 10000, 12), (2**63 + 12345, 2**32 - 5000, 10001, 200000, 12),
+                                      (7, 123456789012, 7777, 50000, 2), (99, 0, 1, 1, 12)]:
+        got = ops.index_sets(seed, first, nb, n, width).cpu().numpy()
+        assert (got == philox.index_sets(seed, first, nb, n, width)).all()
+    whole = ops.index_sets(11, 1000, 30000, 200000)
+    parts = torch.cat([ops.index_sets(11, 1000, 12345, 200000), ops.index_sets(11, 1000 + 12345, 30000 - 12345, 200000)])
+    assert torch.equal(whole, parts)
+    assert ops.index_sets(1, 0, 0, 10).shape == (0, 12)
+    with pytest.raises(Exception):
+        ops.index_sets(1, 0, 10, 0)

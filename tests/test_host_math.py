@@ -137,3 +137,28 @@ def test_t_two_point_matches_golden(lib, golden):
     cnt = np.zeros(B, np.int32)
     lib.h_score_t(ptr(pts), int(m), ptr(T), ctypes.c_int64(B), ctypes.c_double(float(g["thr"])), ptr(cnt))
     np.testing.assert_array_equal(cnt, g["counts"])
+
+
+def test_philox_known_answers_and_host_build(lib):
+    """The oracle's Philox4x32-10 against the published known-answer vectors, and the library's
+    generator (host build of the same header) against the oracle."""
+    from oracle import philox
+
+    for ctr, key, want in philox.KNOWN_ANSWERS:
+        got = philox.philox4x32_10(*[np.array([c], dtype=np.uint32) for c in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+        c = np.array(ctr, dtype=np.uint32); k = np.array(key, dtype=np.uint32); o = np.zeros(4, np.uint32)
+        lib.h_philox4x32_10(ptr(c), ptr(k), ptr(o))
+        assert tuple(int(v) for v in o) == want
+    for seed, first, nb, n, width in [(0, 0, 1000, 10000, 12), (2**63 + 12345, 2**32 - 500, 1000, 200000, 12),
+                                      (7, 123456789012, 777, 3, 2), (99, 0, 64, 1, 12), (5, 10, 300, 2**31 - 1, 2)]:
+        want = philox.index_sets(seed, first, nb, n, width)
+        got = np.zeros((nb, width), np.int32)
+        lib.h_index_sets(ctypes.c_uint64(seed), ctypes.c_uint64(first), ctypes.c_int64(nb), ctypes.c_uint32(n), ctypes.c_int(width), ptr(got))
+        assert (got == want).all()
+        assert want.min() >= 0 and want.max() < n
+    # roughly uniform: a chi-square check over 100 bins of 1.2e6 indices
+    s = philox.index_sets(3, 0, 100000, 100, 12).ravel()
+    h = np.bincount(s, minlength=100)
+    chi2 = ((h - s.size / 100) ** 2 / (s.size / 100)).sum()
+    assert chi2 < 160  # 99 degrees of freedom: P(chi2 > 160) < 1e-4
