@@ -188,6 +188,28 @@ int sfm_lm_translation_f64(const double* K, const double* pts, const int64_t* ca
  * (Runs that must follow the reference's seeded global np.random stream draw on the host.) */
 int sfm_index_sets_i32(uint64_t seed, uint64_t first_id, int64_t nb, int32_t n, int32_t width, int32_t* idx, void* stream);
 
+/* ---- descriptor matching (feature front-end next to the path) ------------------------------
+ * Replaces `cv2.BFMatcher().knnMatch(desc_query, desc_train, k=2)` followed by the ratio test
+ * `m.distance < ratio * n.distance` (src/extract_sift.py:117-123 with ratio 0.4,
+ * src/utils.py:82-86 with ratio 0.75) for SIFT descriptors as OpenCV emits them: 128 integer-valued
+ * components in [0, 255].  Squared distances are exact integers (int8 matrix cores); the reported
+ * distances are their correctly rounded float32 square roots; ties go to the lowest train index.
+ *
+ * sfm_descriptors_to_i8: desc float32[m][128] (or uint8 when src_is_u8) -> desc8 int8[m][128]
+ * (value - 128, 16-byte aligned), norm int32[m] (squared norm of the shifted vector); *bad (device
+ * int32) is set to 1 when a component is not an integer in [0, 255] (results are then meaningless). */
+int sfm_descriptors_to_i8(const void* desc, int32_t src_is_u8, int64_t m, int8_t* desc8, int32_t* norm, int32_t* bad, void* stream);
+
+/* Bytes of device workspace sfm_knn2_ratio_i8 needs for nq queries against nt train descriptors. */
+int64_t sfm_knn2_workspace_bytes(int32_t nq, int32_t nt);
+
+/* For every query: train_idx int32[nq] (nearest train descriptor), dist1/dist2 float32[nq] (distance
+ * to the nearest and to the second nearest), good uint8[nq] = (double)dist1 < ratio * (double)dist2,
+ * *good_count (device int32) = number of good queries.  nt >= 2 (knnMatch with k=2 yields pairs only then). */
+int sfm_knn2_ratio_i8(const int8_t* q8, const int32_t* qnorm, int32_t nq, const int8_t* t8, const int32_t* tnorm, int32_t nt,
+                      double ratio, void* workspace, int64_t workspace_bytes, int32_t* train_idx, float* dist1, float* dist2,
+                      uint8_t* good, int32_t* good_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,8 +1,8 @@
 """SIFT pair extraction with the reference's names (src/extract_sift.py).
 
-This is the OpenCV feature front-end, outside the robust-estimation path: it is kept only so
-that the reference's driver finds the same function and the same cache files.  Needs cv2
-unless both cache files already exist next to the images.
+The feature front-end, next to the robust-estimation path: same function names and the same cache
+files as the reference.  SIFT detection needs cv2 (unless both cache files already exist next to
+the images, or the per-image features are cached); the descriptor matching runs on the GPU.
 """
 from __future__ import annotations
 
@@ -10,25 +10,17 @@ import logging
 import os
 import time
 
-import numpy as np
-
-from .utils import cartesian_to_homogeneous, load_x_pairs, save_x_pairs
+from .utils import load_x_pairs, save_x_pairs
 
 
 def compute_sift_keypoints(image_path1, image_path2):
-    """Reference: src/extract_sift.py:88-135: SIFT on both images, 2-NN brute-force matching,
-    ratio test 0.4; returns (x1 3xN, x2 3xN, descriptors of view 1 128xN)."""
-    try:
-        import cv2
-    except ImportError as e:  # pragma: no cover
-        raise ImportError("compute_sift_keypoints needs OpenCV (cv2)") from e
-    grays = [cv2.cvtColor(cv2.imread(p), cv2.COLOR_BGR2GRAY) for p in (image_path1, image_path2)]
-    sift = cv2.SIFT_create()
-    (kp1, d1), (kp2, d2) = [sift.detectAndCompute(g, None) for g in grays]
-    good = [m for m, n in cv2.BFMatcher().knnMatch(d1, d2, k=2) if m.distance < 0.4 * n.distance]
-    x1 = cartesian_to_homogeneous(np.float32([kp1[m.queryIdx].pt for m in good]).T)
-    x2 = cartesian_to_homogeneous(np.float32([kp2[m.trainIdx].pt for m in good]).T)
-    return x1, x2, np.array([d1[m.queryIdx] for m in good]).T
+    """Reference: src/extract_sift.py:88-135: SIFT on both images (OpenCV, once per image), 2-NN brute-force matching
+    on the GPU, ratio test 0.4; returns (x1 3xN, x2 3xN, descriptors of view 1 128xN)."""
+    from . import matching
+
+    kp1, d1 = matching.image_features(image_path1, "bgr2gray")
+    kp2, d2 = matching.image_features(image_path2, "bgr2gray")
+    return matching.match_keypoints(kp1, d1, kp2, d2, ratio=0.4)
 
 
 def process_sift_for_image_pairs(img_paths, init_pair, dataset):

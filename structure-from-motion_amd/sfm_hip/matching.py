@@ -1,0 +1,103 @@
+"""Descriptor matching on the GPU for the feature front-end (src/extract_sift.py:117-123, src/utils.py:82-86).
+
+The reference matches with ``cv2.BFMatcher().knnMatch(query, train, k=2)`` and a ratio test.  Here the 2-NN search runs
+on the int8 matrix cores (exact integer squared distances) and only SIFT detection itself still needs OpenCV.
+Features of an image are kept per (path, read mode) so that SIFT runs once per image instead of once per call: the
+reference detects every image again in estimate_translation and in refine_translation.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import _capi as C
+from . import ops
+
+# optional directory for per-image feature files (<image name>.<mode>.sift.npz); unset = memory only
+FEATURE_CACHE_DIR = os.environ.get("SFM_HIP_FEATURE_CACHE")
+_features = {}
+
+
+class DescriptorSet:
+    """Descriptors resident on the GPU in the matcher's layout (int8, shifted by -128, with squared norms)."""
+
+    def __init__(self, desc):
+        torch = C.torch_cuda()
+        d = np.asarray(desc)
+        if d.ndim != 2 or d.shape[1] != 128:
+            raise ValueError("descriptors must be [n][128]")
+        if d.dtype != np.uint8:
+            d = np.ascontiguousarray(d, dtype=np.float32)
+        self.n = d.shape[0]
+        self.d8, self.norm = ops.descriptors_to_i8(torch.from_numpy(np.ascontiguousarray(d)).cuda())
+
+
+def _as_set(desc):
+    return desc if isinstance(desc, DescriptorSet) else DescriptorSet(desc)
+
+
+def knn_match_ratio(desc_query, desc_train, ratio):
+    """The good matches of ``knnMatch(desc_query, desc_train, k=2)`` under ``m.distance < ratio * n.distance``, in query
+    order: (query_idx int64[G], train_idx int64[G], distance float32[G]).  Arguments: [n][128] arrays or DescriptorSets."""
+    q, t = _as_set(desc_query), _as_set(desc_train)
+    if q.n == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32)
+    tidx, d1, _, good, _ = ops.knn2_ratio(q.d8, q.norm, t.d8, t.norm, ratio)
+    qi = good.nonzero().flatten()
+    return qi.cpu().numpy(), tidx[qi].to(dtype=C.torch_cuda().int64).cpu().numpy(), d1[qi].cpu().numpy()
+
+
+def image_features(img_path, mode):
+    """SIFT keypoints (float32 [n][2]) and descriptors (uint8 [n][128]) of one image, detected once per (path, mode).
+    mode "bgr2gray": cv2.imread + cvtColor (src/extract_sift.py:104-114); mode "grayscale": cv2.imread(IMREAD_GRAYSCALE)
+    (src/utils.py:78-80).  Needs OpenCV unless the features are cached."""
+    key = (os.path.abspath(img_path), mode)
+    if key in _features:
+        return _features[key]
+    cache = None
+    if FEATURE_CACHE_DIR:
+        cache = os.path.join(FEATURE_CACHE_DIR, f"{os.path.basename(img_path)}.{mode}.sift.npz")
+        if os.path.exists(cache):
+            with np.load(cache) as z:
+                _features[key] = (z["keypoints"], z["descriptors"])
+            return _features[key]
+    try:
+        import cv2
+    except ImportError as e:  # pragma: no cover - depends on the machine
+        raise ImportError("SIFT detection needs OpenCV (cv2); provide cached features or precomputed correspondences") from e
+    if mode == "bgr2gray":
+        gray = cv2.cvtColor(cv2.imread(img_path), cv2.COLOR_BGR2GRAY)
+    elif mode == "grayscale":
+        gray = cv2.imread(img_path, cv2.IMREAD_GRAYSCALE)
+    else:
+        raise ValueError(mode)
+    kps, desc = cv2.SIFT_create().detectAndCompute(gray, None)
+    kp = np.float32([k.pt for k in kps]).reshape(-1, 2)
+    feats = (kp, np.ascontiguousarray(desc).astype(np.uint8) if desc is not None else np.zeros((0, 128), np.uint8))
+    _features[key] = feats
+    if cache:
+        os.makedirs(FEATURE_CACHE_DIR, exist_ok=True)
+        np.savez(cache, keypoints=feats[0], descriptors=feats[1])
+    return feats
+
+
+def match_keypoints(kp1, desc1, kp2, desc2, ratio=0.4):
+    """The array part of compute_sift_keypoints (src/extract_sift.py:116-135): returns
+    (x1 3xN float64 homogeneous, x2 3xN, descriptors of view 1 128xN float32) for the good matches."""
+    qi, ti, _ = knn_match_ratio(desc1, desc2, ratio)
+    one = np.ones((1, qi.size))
+    x1 = np.vstack((np.float32(kp1[qi]).T.reshape(2, -1), one))
+    x2 = np.vstack((np.float32(kp2[ti]).T.reshape(2, -1), one))
+    return x1, x2, np.asarray(desc1)[qi].astype(np.float32).T
+
+
+def correspondences_from_features(kp, desc, desc_X, X0, K, ratio=0.75):
+    """The array part of find_correspondences (src/utils.py:82-93): image features against the descriptors of the
+    reconstructed points; returns (X float32 3xM, x_norm float64 3xM).  desc_X: 128xN array or a DescriptorSet."""
+    train = desc_X if isinstance(desc_X, DescriptorSet) else DescriptorSet(np.ascontiguousarray(np.asarray(desc_X).T))
+    qi, ti, _ = knn_match_ratio(desc, train, ratio)
+    x = np.float32(kp[qi]).T.reshape(2, -1)
+    X = np.float32(np.asarray(X0)[:, ti])
+    x_h = np.vstack((x, np.ones((1, x.shape[1]))))
+    return X, np.linalg.inv(K) @ x_h

@@ -391,3 +391,44 @@ def lm_translation(K, pts, cam_sizes, T0, iters, mu, want_history=False):
     hist = _empty((ncam, iters, 3), torch.float64) if want_history else None
     C.check(lib.sfm_lm_translation_f64(C.dptr(K), C.dptr(pts), C.hptr(off), ncam, C.dptr(T0), int(iters), float(mu), C.dptr(work), C.dptr(T), C.dptr(hist), C.stream_ptr()))
     return (T, hist) if want_history else T
+
+
+# ---- descriptor matching ---------------------------------------------------------------------
+
+
+def descriptors_to_i8(desc):
+    """desc: float32 or uint8 device tensor [m][128], integer valued in [0, 255] (what cv2.SIFT emits).
+    Returns (desc8 int8[m][128] = value - 128, norm int32[m]); raises ValueError on any other content."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    if desc.dim() != 2 or desc.shape[1] != 128 or desc.dtype not in (torch.float32, torch.uint8) or not desc.is_contiguous():
+        raise ValueError("descriptors must be a contiguous float32 or uint8 [m][128] device tensor")
+    m = desc.shape[0]
+    d8 = _empty((m, 128), torch.int8)
+    norm = _empty((m,), torch.int32)
+    bad = _empty((1,), torch.int32)
+    C.check(lib.sfm_descriptors_to_i8(C.dptr(desc), int(desc.dtype == torch.uint8), m, C.dptr(d8), C.dptr(norm), C.dptr(bad), C.stream_ptr()))
+    if m and int(bad.item()) != 0:
+        raise ValueError("descriptor components must be integers in [0, 255] (SIFT descriptors as OpenCV emits them)")
+    return d8, norm
+
+
+def knn2_ratio(q8, qnorm, t8, tnorm, ratio):
+    """2-nearest-neighbour match of every query against the train set + ratio test (cv2.BFMatcher().knnMatch(q, t, k=2)
+    and `m.distance < ratio * n.distance`: src/extract_sift.py:117-123, src/utils.py:82-86).
+    Returns (train_idx int32[nq], dist1 f32[nq], dist2 f32[nq], good uint8[nq], good_count int)."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    nq, nt = q8.shape[0], t8.shape[0]
+    if nt < 2:
+        raise ValueError("need at least two train descriptors (knnMatch with k=2 yields pairs only then)")
+    ws_bytes = int(lib.sfm_knn2_workspace_bytes(nq, nt))
+    ws = _empty((max(16, ws_bytes),), torch.uint8)
+    tidx = _empty((nq,), torch.int32)
+    d1 = _empty((nq,), torch.float32)
+    d2 = _empty((nq,), torch.float32)
+    good = _empty((nq,), torch.uint8)
+    cnt = _empty((1,), torch.int32)
+    C.check(lib.sfm_knn2_ratio_i8(C.dptr(q8), C.dptr(qnorm), nq, C.dptr(t8), C.dptr(tnorm), nt, float(ratio), C.dptr(ws), ws_bytes,
+                                  C.dptr(tidx), C.dptr(d1), C.dptr(d2), C.dptr(good), C.dptr(cnt), C.stream_ptr()))
+    return tidx, d1, d2, good, int(cnt.item())

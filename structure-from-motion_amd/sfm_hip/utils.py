@@ -1,9 +1,9 @@
 """Helpers with the names and signatures of the reference's src/utils.py.
 
 triangulate_3D_point_DLT runs on the GPU; the one-line array helpers are plain NumPy as in
-the reference.  find_correspondences is the OpenCV front-end (SIFT + brute-force matching),
-which is outside the robust-estimation path: it is only a thin cv2 wrapper here and raises if
-OpenCV is not installed.
+the reference.  find_correspondences belongs to the feature front-end: SIFT detection is OpenCV
+(raises if cv2 is not installed and the image's features are not cached), the brute-force
+2-nearest-neighbour matching runs on the GPU (sfm_hip/matching.py).
 """
 from __future__ import annotations
 
@@ -64,19 +64,12 @@ def skew_symmetric_mat(v):
 
 
 def find_correspondences(img_path, desc_X, X0, K):
-    """Reference: src/utils.py:65-93 (front-end, OpenCV).  SIFT on one image, 2-NN brute-force
-    match against the stored descriptors, ratio 0.75; returns (X float32 3xM, x_norm float64 3xM)."""
-    try:
-        import cv2
-    except ImportError as e:  # pragma: no cover - depends on the machine
-        raise ImportError("find_correspondences needs OpenCV (cv2); pass precomputed correspondences instead") from e
-    image = cv2.imread(img_path, cv2.IMREAD_GRAYSCALE)
-    keypoints, descriptors = cv2.SIFT_create().detectAndCompute(image, None)
-    matches = cv2.BFMatcher().knnMatch(descriptors, desc_X.T, k=2)
-    good = [m for m, n in matches if m.distance < 0.75 * n.distance]
-    x = np.float32([keypoints[m.queryIdx].pt for m in good]).T
-    X = np.float32([X0[:, m.trainIdx] for m in good]).T
-    return X, normalize_K(K, cartesian_to_homogeneous(x))
+    """Reference: src/utils.py:65-93.  SIFT on one image (OpenCV, once per image), 2-NN brute-force match against the
+    stored descriptors on the GPU, ratio 0.75; returns (X float32 3xM, x_norm float64 3xM)."""
+    from . import matching
+
+    kp, desc = matching.image_features(img_path, "grayscale")
+    return matching.correspondences_from_features(kp, desc, desc_X, X0, K, ratio=0.75)
 
 
 def log_execution_time(func):
