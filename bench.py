@@ -137,6 +137,23 @@ def secondary_measurements(torch, ops, _capi, synthetic, seed):
     ms = a.elapsed_time(b) / reps
     out["triangulation"] = {"workload": "30000 points, one launch", "ms": ms, "points_per_s": 30000 / (ms * 1e-3),
                             "hbm_bytes": 30000 * (32 + 32)}
+    # descriptor matching (feature front-end): 2-NN + ratio test on the int8 matrix cores
+    out["descriptor_matching"] = []
+    for nq, nt in [(8000, 8000), (50000, 50000)]:
+        g = torch.Generator(device="cuda").manual_seed(seed + nq)
+        q8, qn = ops.descriptors_to_i8(torch.randint(0, 256, (nq, 128), dtype=torch.uint8, device="cuda", generator=g))
+        t8, tn = ops.descriptors_to_i8(torch.randint(0, 256, (nt, 128), dtype=torch.uint8, device="cuda", generator=g))
+        ops.knn2_ratio(q8, qn, t8, tn, 0.75)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            ops.knn2_ratio(q8, qn, t8, tn, 0.75)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        out["descriptor_matching"].append({"workload": f"{nq} query x {nt} train SIFT descriptors (uint8 x 128), k=2 + ratio test",
+                                           "ms": ms, "int8_tops": 2.0 * 128 * nq * nt / (ms * 1e-3) / 1e12,
+                                           "pairs_per_s": float(nq) * nt / (ms * 1e-3)})
     return out
 
 

@@ -6,7 +6,8 @@
 // with scalar loads into SGPRs; the VALU only executes the residual arithmetic, with the
 // model in VGPRs and the point as the scalar operand of each instruction.  Counts are
 // accumulated per lane (compare + add-with-carry), so no cross-lane reduction is needed.
-// Nothing is GEMM shaped; there is no MFMA in this library.
+// Nothing in this file is GEMM shaped, so there is no MFMA here (the descriptor matcher in
+// sfm_match.hip is the one matrix-core kernel of the library).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
