@@ -233,6 +233,9 @@ def main():
     ap.add_argument("--index-source", choices=["auto", "legacy", "philox"], default="auto",
                     help="legacy: np.random.randint on the host, as the reference draws its samples; philox: generated on the device "
                     "from (seed, global hypothesis id), identical under any sharding; auto = legacy on one GPU, philox on several")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N>1: nccl (= RCCL over xGMI, one GPU per rank); gloo only to rehearse the "
+                    "multi-rank path on a box with fewer GPUs than ranks (ranks then share GPUs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the T-RANSAC / LM / triangulation timings")
     ap.add_argument("--e2e", action="store_true", help="only run the synthetic dataset-5-shaped end-to-end geometry and print it")
     ap.add_argument("--e2e-cpu", action="store_true", help="with --e2e: also time the NumPy oracle end to end (minutes) and compare")
@@ -251,9 +254,15 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    key_device = "cuda" if args.backend == "nccl" else "cpu"
     _capi.load_library()
 
     if args.e2e:
@@ -284,7 +293,7 @@ def main():
     xmax = float(np.abs(np.concatenate([x1n[:2], x2n[:2]])).max())
     ce = torch.empty(B, dtype=torch.int32, device="cuda")
     ch = torch.empty(B, dtype=torch.int32, device="cuda")
-    best = torch.zeros(2, dtype=torch.int64, device="cuda")
+    best = torch.zeros(2, dtype=torch.int64, device=key_device)
     last_stats = {}
     workspace = ops.eh_best_workspace(B)
 
@@ -308,7 +317,7 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=key_device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
