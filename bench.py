@@ -172,7 +172,7 @@ def sweep(torch, ops, _capi, synthetic, orc, seed):
         idx = ops.index_sets(seed, 0, B, n)  # generated on the device from (seed, hypothesis id)
         ce = torch.empty(B, dtype=torch.int32, device="cuda")
         ch = torch.empty(B, dtype=torch.int32, device="cuda")
-        ws = ops.eh_best_workspace(B)
+        ws = ops.eh_best_workspace(B, n)
         for _ in range(3 if B * n < 5e11 else 1):
             ops.eh_best_native(corr, corr32, idx, thr, 3 * thr, xmax, workspace=ws)
         torch.cuda.synchronize()
@@ -295,7 +295,7 @@ def main():
     ch = torch.empty(B, dtype=torch.int32, device="cuda")
     best = torch.zeros(2, dtype=torch.int64, device=key_device)
     last_stats = {}
-    workspace = ops.eh_best_workspace(B)
+    workspace = ops.eh_best_workspace(B, n)
 
     def step():
         # one library call: float32 bounds for all hypotheses -> candidates -> float64 re-score -> exact winners

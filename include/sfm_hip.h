@@ -63,17 +63,18 @@ int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const i
 
 /* The whole arg-max step as one call: the exact winners of a block of hypotheses, i.e. the first
  * maximum of the counts sfm_eh_score_f64 would return (largest count, lowest id), for E and for H.
- * Internally a cascade of upper bounds: float32 bounds for all hypotheses (loose != 0: the cheaper
- * one-sided/box forms) -> exact count of the hypothesis with the largest bound -> candidates whose
+ * Internally a cascade of upper bounds: float32 bounds for all hypotheses (loose = 0: the tight
+ * forms; 1: the cheaper one-sided/box forms on the vector ALU; 2: the same forms with E x1 and H x1 on
+ * the bf16 matrix cores, the fastest) -> exact count of the hypothesis with the largest bound -> candidates whose
  * bound reaches it -> tight float32 bounds when there are many -> float64 for the rest.  Replaces
  * the best-so-far bookkeeping of src/ransac_algorithm.py:102-106 and :121-125 over nb iterations
  * when only the final winner is wanted.
- * workspace: device scratch of at least sfm_eh_best_workspace_bytes(nb) bytes (nothing is
- * allocated on the device here).  result (HOST, int64[8]): count_e, index_e, count_h, index_h,
+ * workspace: device scratch of at least sfm_eh_best_workspace_bytes(nb, n) bytes, 256-byte aligned
+ * (nothing is allocated on the device here).  result (HOST, int64[8]): count_e, index_e, count_h, index_h,
  * candidates_e, candidates_h, re-bounded candidates, hypotheses scored in float64.
  * Unlike the other entry points this one synchronises `stream` (it reads a few words back to decide
  * the next level). */
-int64_t sfm_eh_best_workspace_bytes(int64_t nb);
+int64_t sfm_eh_best_workspace_bytes(int64_t nb, int32_t n);
 int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
                 double xmax, double safety, int32_t loose, void* workspace, int64_t workspace_bytes, int64_t* result,
                 void* stream);
@@ -187,6 +188,16 @@ int sfm_lm_translation_f64(const double* K, const double* pts, const int64_t* ca
  * width: 12 (E/H, idx int32[nb][12], 16-byte aligned) or 2 (translation, idx int32[nb][2]).
  * (Runs that must follow the reference's seeded global np.random stream draw on the host.) */
 int sfm_index_sets_i32(uint64_t seed, uint64_t first_id, int64_t nb, int32_t n, int32_t width, int32_t* idx, void* stream);
+
+/* Matrix-core form of the loose float32 bounds (same meaning and guarantees as sfm_eh_upper_f32 with
+ * one_sided = 1: up >= exact count for every hypothesis).  The 3x3 products E x1 and H x1 of
+ * src/ransac_algorithm.py:206-207 and :320 run on the bf16 matrix cores from three-piece bf16 splits
+ * of the float64 models and coordinates; the rest of the two tests stays on the vector ALU.
+ * corrm: match-side operands written by sfm_corr_to_mfma (sfm_corr_mfma_bytes(n) bytes, 16-byte aligned). */
+int64_t sfm_corr_mfma_bytes(int32_t n);
+int sfm_corr_to_mfma(const double* corr, int32_t n, void* corrm, void* stream);
+int sfm_eh_upper_mfma_f32(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e,
+                          double thr_h, double xmax, double safety, int32_t* up_e, int32_t* up_h, void* stream);
 
 /* ---- descriptor matching (feature front-end next to the path) ------------------------------
  * Replaces `cv2.BFMatcher().knnMatch(desc_query, desc_train, k=2)` followed by the ratio test

@@ -280,6 +280,222 @@ __global__ __launch_bounds__(kBlock) void eh_upper_kernel(const double4* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Matrix-core form of the loose pre-filter.  The products l = E x1 and (hx, hy, hz) = H x1 over
+// all (hypothesis, match) pairs are two [3B x 3] x [3 x N] GEMMs, so they run on the bf16 matrix
+// cores at float32-like accuracy: every model entry a and every coordinate x is split into three
+// bf16 pieces (a = a0 + a1 + a2 + r, |r| <= 2^-26 |a|) and a.x is expanded into the six piece
+// products of weight >= 2^-18 (a0x0, a0x1, a1x0, a0x2, a2x0, a1x1); with the constant third
+// coordinate one row of the product is a K = 6 + 6 + 3 = 15 contraction = ONE
+// v_mfma_f32_32x32x16_bf16 per 32 matches x 32 hypotheses, a quarter of the VALU time of the
+// two fmas it replaces.  The VALU keeps only what is not GEMM shaped (s = l.x2, |l|^2, the
+// box test): 14 instead of 26 instructions per pair, all on VGPR operands.
+//
+// A wave solves 64 hypotheses (one per lane, float64, as everywhere else), publishes their
+// piece vectors through LDS and then owns two column blocks of 32 hypotheses; in the 32x32
+// accumulator layout a lane holds ONE hypothesis column and 16 matches, so the per-hypothesis
+// constants stay per-lane values and the counts need one cross-half add at the end.
+//
+// Error bound used for the slack (upper-bound property): piece expansion (dropped products and
+// residuals) <= 2^-24 R, accumulation inside the matrix core <= 32 * 2^-24 R for any summation
+// order with rounding or truncation to float32 at every step (profiles/microbench/mfma_bf16_accum
+// measures <= 4.7 * 2^-24 on this chip), R = sum of |a||x| over the row.
+// ---------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr double kEpsMfma = 34.0 * kEps32;
+
+__device__ __forceinline__ unsigned bf16_rn_bits(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// v = p[0] + p[1] + p[2] + r with bf16 pieces p and |r| <= 2^-26 |v|
+__device__ __forceinline__ void split3_bf16(double v, unsigned (&p)[3]) {
+  double r = v;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    p[i] = bf16_rn_bits((float)r);
+    r -= (double)__uint_as_float(p[i] << 16);
+  }
+}
+
+// the 16 bf16 of one operand vector as two uint4 (k = 0..7, 8..15); `model` selects the
+// hypothesis-side order (a0 a0 a1 a0 a2 a1 | b.. | c0 c1 c2 0), else the match-side order
+// (x0 x1 x0 x2 x0 x1 | y.. | 1 1 1 0), so that element k of one times element k of the other
+// enumerates the kept piece products.
+__device__ __forceinline__ void pack_pieces(double a, double b, double c, bool model, uint4& lo, uint4& hi) {
+  unsigned pa[3], pb[3], pc[3];
+  split3_bf16(a, pa);
+  split3_bf16(b, pb);
+  unsigned e[16];
+  if (model) {
+    split3_bf16(c, pc);
+    e[0] = pa[0]; e[1] = pa[0]; e[2] = pa[1]; e[3] = pa[0]; e[4] = pa[2]; e[5] = pa[1];
+    e[6] = pb[0]; e[7] = pb[0]; e[8] = pb[1]; e[9] = pb[0]; e[10] = pb[2]; e[11] = pb[1];
+    e[12] = pc[0]; e[13] = pc[1]; e[14] = pc[2]; e[15] = 0;
+  } else {
+    e[0] = pa[0]; e[1] = pa[1]; e[2] = pa[0]; e[3] = pa[2]; e[4] = pa[0]; e[5] = pa[1];
+    e[6] = pb[0]; e[7] = pb[1]; e[8] = pb[0]; e[9] = pb[2]; e[10] = pb[0]; e[11] = pb[1];
+    e[12] = 0x3F80u; e[13] = 0x3F80u; e[14] = 0x3F80u; e[15] = 0;
+  }
+  lo = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+  hi = make_uint4(e[8] | (e[9] << 16), e[10] | (e[11] << 16), e[12] | (e[13] << 16), e[14] | (e[15] << 16));
+}
+
+// Match-side operands for the matrix-core pre-filter: pieces[npad][2] (the 16 bf16 of (x1, y1, 1)) and
+// xy[npad] = float32 (x2, y2); npad = n rounded up to 32, the padding scores as an outlier (NaN).
+__global__ __launch_bounds__(kBlock) void corr_to_mfma_kernel(const double4* __restrict__ corr, int n, int npad, uint4* __restrict__ pieces,
+                                                              float2* __restrict__ xy) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= npad) return;
+  if (j < n) {
+    const double4 c = corr[j];
+    uint4 lo, hi;
+    pack_pieces(c.x, c.y, 1.0, false, lo, hi);
+    pieces[2 * j] = lo;
+    pieces[2 * j + 1] = hi;
+    xy[j] = make_float2((float)c.z, (float)c.w);
+  } else {
+    pieces[2 * j] = make_uint4(0, 0, 0, 0);
+    pieces[2 * j + 1] = make_uint4(0, 0, 0, 0);
+    const float qnan = __builtin_nanf("");
+    xy[j] = make_float2(qnan, qnan);
+  }
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+__global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
+                                                                  const float2* __restrict__ xy, int n, const int32_t* __restrict__ idx,
+                                                                  long long nb, double two_thr_e2, double thr_h2, double xmax, double safety,
+                                                                  int* __restrict__ up_e, int* __restrict__ up_h, int tiles_per_split,
+                                                                  int use_atomics) {
+  __shared__ uint4 bstage[kBlock / 64][64][6][2];
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long hyp = gid < nb ? gid : nb - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  float k1_own, c_own, rt_own, g_own;
+  {
+    double Ed[9], Hd[9], A[9];
+    float unused[9];
+    {
+      double p8[8][4], p4[4][4];
+      gather_samples<double>(corr, idx + 12 * hyp, p8, p4);
+      solve_E8<double>(p8, Ed);
+      solve_H4<double>(p4, Hd);
+    }
+    double inv = to_unit_f32(Ed, unused, A);
+    {
+      const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
+      // |s - s_true|: errors of l0, l1, l2 carried through s = l0 x2 + l1 y2 + l2, float32 rounding of x2, y2 and of the two fmas
+      const double Es = (kEpsMfma + 4.0 * kEps32) * (xmax * (R0 + R1) + R2);
+      // |L - L_true|, L = |(l0, l1)|: errors of l0 and l1 plus the float32 evaluation of l0^2 + l1^2
+      const double eL = (kEpsMfma + 2.0 * kEps32) * (R0 + R1);
+      const double rk = sqrt(two_thr_e2);
+      const double G = safety * (Es + rk * eL);
+      double mu = 2.0 * G / rk;  // balances the two slack terms for epipolar lines of norm ~0.5
+      mu = mu < 1.0e-3 ? 1.0e-3 : (mu > 0.25 ? 0.25 : mu);
+      k1_own = round_up_f32(two_thr_e2 * (1.0 + mu) * (1.0 + 16.0 * kEps32));
+      c_own = round_up_f32(G * G * (1.0 + 1.0 / mu) * (1.0 + 16.0 * kEps32));
+    }
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+      pack_pieces(Ed[3 * v] * inv, Ed[3 * v + 1] * inv, Ed[3 * v + 2] * inv, true, bstage[wave][lane][v][0], bstage[wave][lane][v][1]);
+    inv = to_unit_f32(Hd, unused, A);
+    {
+      const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
+      const double ez = kEpsMfma * R2;
+      const double Dx = (kEpsMfma + 3.0 * kEps32) * (R0 + xmax * R2), Dy = (kEpsMfma + 3.0 * kEps32) * (R1 + xmax * R2);
+      const double rt = sqrt(thr_h2);
+      const double G = safety * (rt * ez + Dx + Dy);
+      rt_own = round_up_f32(rt * (1.0 + 16.0 * kEps32));
+      g_own = round_up_f32(G * (1.0 + 16.0 * kEps32));
+    }
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+      pack_pieces(Hd[3 * v] * inv, Hd[3 * v + 1] * inv, Hd[3 * v + 2] * inv, true, bstage[wave][lane][3 + v][0], bstage[wave][lane][3 + v][1]);
+  }
+  __syncthreads();
+  bf16x8 B[2][6];
+  float k1[2], cc[2], rt[2], gg[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+#pragma unroll
+    for (int v = 0; v < 6; ++v) B[k][v] = as_bf16x8(bstage[wave][32 * k + col][v][half]);
+    k1[k] = __shfl(k1_own, 32 * k + col);
+    cc[k] = __shfl(c_own, 32 * k + col);
+    rt[k] = __shfl(rt_own, 32 * k + col);
+    gg[k] = __shfl(g_own, 32 * k + col);
+  }
+  // accumulator register i of a lane in half h is matrix row (i&3) + 8(i>>2) + 4h; the A row that
+  // lane `col` supplies is loaded from the match whose position in the tile is 16h' + i for that row,
+  // so that half h scores the 16 consecutive matches 16h .. 16h+15 of the tile
+  const int apos = 16 * ((col >> 2) & 1) + (col & 3) + 4 * (col >> 3);
+  const int ntiles = (n + 31) / 32;
+  const int t0 = blockIdx.y * tiles_per_split;
+  const int t1 = min(ntiles, t0 + tiles_per_split);
+  int ce[2] = {0, 0}, ch[2] = {0, 0};
+  const f32x16 zero = {0};
+  for (int t = t0; t < t1; ++t) {
+    const bf16x8 A = as_bf16x8(pieces[2 * (t * 32 + apos) + half]);
+    float x2[16], y2[16];
+    {
+      const float4* q = reinterpret_cast<const float4*>(xy + t * 32 + 16 * half);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 v = q[i];
+        x2[2 * i] = v.x; y2[2 * i] = v.y; x2[2 * i + 1] = v.z; y2[2 * i + 1] = v.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      {
+        const f32x16 l0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][0], zero, 0, 0, 0);
+        const f32x16 l1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][1], zero, 0, 0, 0);
+        const f32x16 l2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][2], zero, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float s = fma(l0[i], x2[i], fma(l1[i], y2[i], l2[i]));
+          const float n1 = fma(l0[i], l0[i], l1[i] * l1[i]);
+          ce[k] += (fma(s, s, -cc[k]) < k1[k] * n1) ? 1 : 0;
+        }
+      }
+      {
+        const f32x16 hx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][3], zero, 0, 0, 0);
+        const f32x16 hy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][4], zero, 0, 0, 0);
+        const f32x16 hz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][5], zero, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float dx = fma(x2[i], hz[i], -hx[i]);
+          const float dy = fma(y2[i], hz[i], -hy[i]);
+          const float lim = fma(rt[k], fabsf(hz[i]), gg[k]);
+          ch[k] += ((fabsf(dx) < lim) & (fabsf(dy) < lim)) ? 1 : 0;
+        }
+      }
+    }
+  }
+  // the two halves of the wave scored different matches for the same 32 hypotheses
+  int se[2], sh[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    se[k] = ce[k] + __shfl_xor(ce[k], 32);
+    sh[k] = ch[k] + __shfl_xor(ch[k], 32);
+  }
+  const int oute = half ? se[1] : se[0], outh = half ? sh[1] : sh[0];  // lane L reports hypothesis L = 32*half + col
+  if (gid < nb) {
+    if (use_atomics) {
+      atomicAdd(up_e + gid, oute);
+      atomicAdd(up_h + gid, outh);
+    } else {
+      up_e[gid] = oute;
+      up_h[gid] = outh;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void corr_to_f32_kernel(const double4* __restrict__ corr, int n, float4* __restrict__ corr32) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) {
@@ -884,7 +1100,7 @@ const char* sfm_hip_error_string(int code) {
   return hipGetErrorString((hipError_t)code);
 }
 
-int sfm_hip_abi_version(void) { return 1; }
+int sfm_hip_abi_version(void) { return 2; }
 
 static int launch_eh_score(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, int32_t* count_e,
                            int32_t* count_h, hipStream_t st) {
@@ -957,19 +1173,68 @@ int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const i
   return launch_eh_upper(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, one_sided, up_e, up_h, (hipStream_t)stream);
 }
 
+// match-side operands of the matrix-core pre-filter: [npad][32 B] piece vectors, then [npad] float2
+static inline int padded32(int n) { return (n + 31) & ~31; }
+
+int64_t sfm_corr_mfma_bytes(int32_t n) { return n <= 0 ? 0 : (int64_t)padded32(n) * 40; }
+
+static int launch_corr_to_mfma(const double* corr, int32_t n, void* corrm, hipStream_t st) {
+  if (!corr || !corrm || n <= 0 || ((uintptr_t)corrm & 15u) != 0) return SFM_EINVAL;
+  const int npad = padded32(n);
+  corr_to_mfma_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, (uint4*)corrm,
+                                                               (float2*)((char*)corrm + (size_t)npad * 32));
+  return check_launch();
+}
+
+int sfm_corr_to_mfma(const double* corr, int32_t n, void* corrm, void* stream) {
+  clear_stale_error();
+  return launch_corr_to_mfma(corr, n, corrm, (hipStream_t)stream);
+}
+
+static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
+                                double xmax, double safety, int32_t* up_e, int32_t* up_h, hipStream_t st) {
+  if (!corr || !corrm || !idx || !up_e || !up_h || n <= 0 || nb < 0 || ((uintptr_t)corrm & 15u) != 0) return SFM_EINVAL;
+  if (!(xmax > 0.0 && xmax < 1.0e6 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
+  if (nb == 0) return 0;
+  const long long tiles = (nb + kBlock - 1) / kBlock;
+  if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
+  const int npad = padded32(n);
+  const int ntiles = npad / 32;
+  int splits = choose_splits(tiles, n);
+  if (splits > ntiles) splits = ntiles;
+  const int tps = div_up(ntiles, splits);
+  if (splits > 1) {
+    hipError_t e = hipMemsetAsync(up_e, 0, sizeof(int32_t) * nb, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(up_h, 0, sizeof(int32_t) * nb, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  eh_upper_mfma_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>(
+      (const double4*)corr, (const uint4*)corrm, (const float2*)((const char*)corrm + (size_t)npad * 32), n, idx, nb, 2.0 * thr_e * thr_e,
+      thr_h * thr_h, xmax, safety, up_e, up_h, tps, splits > 1);
+  return check_launch();
+}
+
+int sfm_eh_upper_mfma_f32(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
+                          double xmax, double safety, int32_t* up_e, int32_t* up_h, void* stream) {
+  clear_stale_error();
+  return launch_eh_upper_mfma(corr, corrm, n, idx, nb, thr_e, thr_h, xmax, safety, up_e, up_h, (hipStream_t)stream);
+}
+
 // ---- the whole bound cascade as one call -------------------------------------------------
 namespace {
 constexpr int kCandCap = 65536;      // candidates kept per class; more than that -> score everything in float64
 constexpr int kTightenAbove = 4096;  // more candidates than this are first re-bounded with the tight float32 tests
 
 struct BestWs {
+  void* corrm;
   int *up_e, *up_h, *lead_counts, *sc_e, *sc_h;
   unsigned long long *keys, *n2;
   BestInfo* info;
   int32_t *lead_rows, *cand_e, *cand_h, *cand2, *rows;
 };
 
-inline size_t carve(char* base, int64_t nb, BestWs* w) {
+inline size_t carve(char* base, int64_t nb, int32_t n, BestWs* w) {
   size_t off = 0;
   auto take = [&](size_t bytes) {
     char* p = base ? base + off : nullptr;
@@ -989,13 +1254,14 @@ inline size_t carve(char* base, int64_t nb, BestWs* w) {
   w->rows = (int32_t*)take(sizeof(int32_t) * 12 * 2 * kCandCap);
   w->sc_e = (int*)take(sizeof(int) * 2 * kCandCap);
   w->sc_h = (int*)take(sizeof(int) * 2 * kCandCap);
+  w->corrm = take((size_t)((n + 31) & ~31) * 40);
   return off;
 }
 }  // namespace
 
-int64_t sfm_eh_best_workspace_bytes(int64_t nb) {
+int64_t sfm_eh_best_workspace_bytes(int64_t nb, int32_t n) {
   BestWs w;
-  return nb < 0 ? -1 : (int64_t)carve(nullptr, nb, &w);
+  return (nb < 0 || n < 0) ? -1 : (int64_t)carve(nullptr, nb, n, &w);
 }
 
 #define SFM_TRY(expr)            \
@@ -1009,11 +1275,16 @@ int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_
   clear_stale_error();
   if (!corr || !corr32 || !idx || !workspace || !result || n <= 0 || nb <= 0 || (uint64_t)nb > 0x7FFFFFFFull) return SFM_EINVAL;
   BestWs w;
-  if ((int64_t)carve((char*)workspace, nb, &w) > workspace_bytes) return SFM_EINVAL;
+  if (((uintptr_t)workspace & 255u) != 0 || (int64_t)carve((char*)workspace, nb, n, &w) > workspace_bytes) return SFM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   for (int i = 0; i < 8; ++i) result[i] = 0;
   // level 1: float32 bounds for every hypothesis, leaders, their exact counts, candidate lists
-  SFM_TRY(launch_eh_upper(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, loose, w.up_e, w.up_h, st));
+  if (loose == 2) {
+    SFM_TRY(launch_corr_to_mfma(corr, n, w.corrm, st));
+    SFM_TRY(launch_eh_upper_mfma(corr, w.corrm, n, idx, nb, thr_e, thr_h, xmax, safety, w.up_e, w.up_h, st));
+  } else {
+    SFM_TRY(launch_eh_upper(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, loose, w.up_e, w.up_h, st));
+  }
   SFM_TRY(hipMemsetAsync(w.keys, 0, 256 * 3, st));  // keys, n2, info (three consecutive 256-byte slots)
   {
     const long long tiles = (nb + kBlock - 1) / kBlock;

@@ -22,7 +22,7 @@ _SIGS = {
     "sfm_eh_score_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _P, _P, _P]),
     "sfm_corr_to_f32": (_c.c_int, [_P, _c.c_int32, _P, _P]),
     "sfm_eh_upper_f32": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int32, _P, _P, _P]),
-    "sfm_eh_best_workspace_bytes": (_c.c_int64, [_c.c_int64]),
+    "sfm_eh_best_workspace_bytes": (_c.c_int64, [_c.c_int64, _c.c_int32]),
     "sfm_eh_best": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int32, _P,
                                _c.c_int64, _P, _P]),
     "sfm_eh_models_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _P, _P, _P, _P]),
@@ -44,6 +44,9 @@ _SIGS = {
     "sfm_t_models_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _P, _P]),
     "sfm_lm_translation_f64": (_c.c_int, [_P, _P, _P, _c.c_int32, _P, _c.c_int32, _c.c_double, _P, _P, _P, _P]),
     "sfm_index_sets_i32": (_c.c_int, [_c.c_uint64, _c.c_uint64, _c.c_int64, _c.c_int32, _c.c_int32, _P, _P]),
+    "sfm_corr_mfma_bytes": (_c.c_int64, [_c.c_int32]),
+    "sfm_corr_to_mfma": (_c.c_int, [_P, _c.c_int32, _P, _P]),
+    "sfm_eh_upper_mfma_f32": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _P, _P, _P]),
     "sfm_descriptors_to_i8": (_c.c_int, [_P, _c.c_int32, _c.c_int64, _P, _P, _P, _P]),
     "sfm_knn2_workspace_bytes": (_c.c_int64, [_c.c_int32, _c.c_int32]),
     "sfm_knn2_ratio_i8": (_c.c_int, [_P, _P, _c.c_int32, _P, _P, _c.c_int32, _c.c_double, _P, _c.c_int64, _P, _P, _P, _P, _P, _P]),

@@ -76,22 +76,49 @@ def eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, out=None, one_si
     return ue, uh
 
 
-def eh_best_workspace(nb):
-    """Device scratch for eh_best_native (uint8 tensor)."""
+def corr_to_mfma(corr):
+    """Match-side operands of the matrix-core pre-filter (bf16 piece vectors of (x1, y1, 1) + float32 (x2, y2))."""
     torch = C.torch_cuda()
     lib = C.load_library()
-    return _empty((int(lib.sfm_eh_best_workspace_bytes(int(nb))),), torch.uint8)
+    n = corr.shape[0]
+    corrm = _empty((int(lib.sfm_corr_mfma_bytes(n)),), torch.uint8)
+    C.check(lib.sfm_corr_to_mfma(C.dptr(corr), n, C.dptr(corrm), C.stream_ptr()))
+    return corrm
 
 
-def eh_best_native(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, loose=True, workspace=None):
-    """The bound cascade as ONE library call (sfm_eh_best).  Same result as eh_best below."""
+def eh_upper_mfma(corr, corrm, idx, thr_e, thr_h, xmax, safety=2.0, out=None):
+    """Loose float32 upper bounds like eh_upper(one_sided=True), with E x1 and H x1 on the bf16 matrix cores."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    nb = idx.shape[0]
+    if out is None:
+        ue = _empty((nb,), torch.int32)
+        uh = _empty((nb,), torch.int32)
+    else:
+        ue, uh = out
+    C.check(lib.sfm_eh_upper_mfma_f32(C.dptr(corr), C.dptr(corrm), corr.shape[0], C.dptr(idx), nb, float(thr_e), float(thr_h),
+                                      float(xmax), float(safety), C.dptr(ue), C.dptr(uh), C.stream_ptr()))
+    return ue, uh
+
+
+def eh_best_workspace(nb, n):
+    """Device scratch for eh_best_native over nb hypotheses and n matches (uint8 tensor)."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    return _empty((int(lib.sfm_eh_best_workspace_bytes(int(nb), int(n))),), torch.uint8)
+
+
+def eh_best_native(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, loose=2, workspace=None):
+    """The bound cascade as ONE library call (sfm_eh_best).  Same result as eh_best below.
+    loose: first level = 0 tight float32 bounds, 1 loose bounds on the vector ALU, 2 loose bounds with the
+    3x3 products on the bf16 matrix cores (default, fastest)."""
     lib = C.load_library()
     nb = idx.shape[0]
     if workspace is None:
-        workspace = eh_best_workspace(nb)
+        workspace = eh_best_workspace(nb, corr.shape[0])
     res = np.zeros(8, np.int64)
     C.check(lib.sfm_eh_best(C.dptr(corr), C.dptr(corr32), corr.shape[0], C.dptr(idx), nb, float(thr_e), float(thr_h), float(xmax), float(safety),
-                            int(bool(loose)), C.dptr(workspace), workspace.numel(), C.hptr(res), C.stream_ptr()))
+                            int(loose), C.dptr(workspace), workspace.numel(), C.hptr(res), C.stream_ptr()))
     stats = {"candidates_e": int(res[4]), "candidates_h": int(res[5]), "tightened": int(res[6]), "rescored_f64": int(res[7])}
     return (int(res[0]), int(res[1])), (int(res[2]), int(res[3])), stats
 

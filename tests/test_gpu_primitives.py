@@ -280,8 +280,10 @@ def test_loose_bound_cascade_is_exact(ops, dev, inl, pl, n, B, seed, monkeypatch
         assert (cH, iH) == (int(ch.max()), int(np.argmax(ch))), stats
 
 
-@pytest.mark.parametrize("inl,pl,n,B,seed,loose", [(0.3, 0.5, 5000, 100000, 0, True), (0.3, 0.5, 5000, 100000, 0, False),
-                                                   (0.0, 0.5, 3000, 200000, 6, True), (0.05, 0.5, 777, 70001, 3, True)])
+@pytest.mark.parametrize("inl,pl,n,B,seed,loose", [(0.3, 0.5, 5000, 100000, 0, 1), (0.3, 0.5, 5000, 100000, 0, 0),
+                                                   (0.0, 0.5, 3000, 200000, 6, 1), (0.05, 0.5, 777, 70001, 3, 1),
+                                                   (0.3, 0.5, 5000, 100000, 0, 2), (0.0, 0.5, 3000, 200000, 6, 2),
+                                                   (0.05, 0.5, 777, 70001, 3, 2), (0.6, 1.0, 31, 1000, 4, 2), (0.5, 0.0, 33, 257, 5, 2)])
 def test_native_cascade_entry_point(ops, dev, inl, pl, n, B, seed, loose):
     """sfm_eh_best (the whole cascade inside the library, caller-provided workspace) returns the
     first maximum of the float64 counts, also when thousands of candidates go through the tight
@@ -294,7 +296,7 @@ def test_native_cascade_entry_point(ops, dev, inl, pl, n, B, seed, loose):
     idx = dev(np.random.default_rng(seed).integers(0, n, size=(B, 12)), np.int32)
     thr = 1.0 / sc["K"][0][0]
     ce, ch = [t.cpu().numpy() for t in ops.eh_score(corr, idx, thr, 3 * thr)]
-    ws = ops.eh_best_workspace(B)
+    ws = ops.eh_best_workspace(B, n)
     for _ in range(2):  # the workspace is reused: stale contents must not matter
         (cE, iE), (cH, iH), stats = ops.eh_best_native(corr, c32, idx, thr, 3 * thr, xmax, loose=loose, workspace=ws)
         assert (cE, iE) == (int(ce.max()), int(np.argmax(ce))), stats
@@ -325,10 +327,11 @@ def test_native_cascade_many_loose_survivors(ops, dev):
     idx = dev(np.random.default_rng(8).integers(0, n, size=(B, 12)), np.int32)
     thr = 1.0 / sc["K"][0][0]
     ce, ch = [t.cpu().numpy() for t in ops.eh_score(corr, idx, thr, 3 * thr)]
-    (cE, iE), (cH, iH), stats = ops.eh_best_native(corr, ops.corr_to_f32(corr), idx, thr, 3 * thr, float(np.abs(corr_h).max()))
-    assert (cE, iE) == (int(ce.max()), int(np.argmax(ce))), stats
-    assert (cH, iH) == (int(ch.max()), int(np.argmax(ch))), stats
-    assert stats["candidates_e"] > 65536 and stats["tightened"] == B and stats["rescored_f64"] < B, stats
+    for loose in (1, 2):
+        (cE, iE), (cH, iH), stats = ops.eh_best_native(corr, ops.corr_to_f32(corr), idx, thr, 3 * thr, float(np.abs(corr_h).max()), loose=loose)
+        assert (cE, iE) == (int(ce.max()), int(np.argmax(ce))), stats
+        assert (cH, iH) == (int(ch.max()), int(np.argmax(ch))), stats
+        assert stats["candidates_e"] > 65536 and stats["tightened"] == B and stats["rescored_f64"] < B, stats
 
 
 def test_device_index_sets_match_oracle_and_are_sharding_invariant(ops):
@@ -347,3 +350,21 @@ def test_device_index_sets_match_oracle_and_are_sharding_invariant(ops):
     assert ops.index_sets(1, 0, 0, 10).shape == (0, 12)
     with pytest.raises(Exception):
         ops.index_sets(1, 0, 10, 0)
+
+
+@pytest.mark.parametrize("n,B,inl,seed", [(1500, 20000, 0.5, 1), (10000, 50000, 0.3, 0), (97, 4099, 0.8, 2), (32, 64, 0.9, 3), (5000, 3000, 0.0, 4)])
+def test_matrix_core_bounds_are_upper_bounds(ops, dev, n, B, inl, seed):
+    """sfm_eh_upper_mfma_f32 (E x1 and H x1 on the bf16 matrix cores from three-piece splits): never below the exact
+    float64 count, and about as tight as the vector-ALU form of the same tests."""
+    sc, x1, x2 = scene(n=n, inl=inl, pl=0.5, seed=seed)
+    corr_h = ops.pack_corr(x1, x2)
+    corr = dev(corr_h)
+    xmax = float(np.abs(corr_h).max())
+    idx = ops.index_sets(seed, 0, B, n)
+    thr = 1.0 / sc["K"][0][0]
+    ce, ch = ops.eh_score(corr, idx, thr, 3 * thr)
+    me, mh = ops.eh_upper_mfma(corr, ops.corr_to_mfma(corr), idx, thr, 3 * thr, xmax)
+    ve, vh = ops.eh_upper(corr, ops.corr_to_f32(corr), idx, thr, 3 * thr, xmax, one_sided=True)
+    assert int((me < ce).sum()) == 0 and int((mh < ch).sum()) == 0
+    assert float((me - ce).double().mean()) <= float((ve - ce).double().mean()) * 1.2 + 0.5
+    assert float((mh - ch).double().mean()) <= float((vh - ch).double().mean()) * 1.2 + 0.5
