@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profiling recipe used for the summaries in this directory (run on the GPU box through gpurun):
 #   bash profiles/run_profile.sh <tag>
-# Pass 1: kernel trace + stats of the default bench command.  Passes 2-5: PMC counters, one block
+# Pass 1: kernel trace + stats of the default bench command.  Passes 2-6: PMC counters, one block
 # of counters per run, on a short run of the same workload (counters are per dispatch).
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -16,6 +16,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- pyt
 [ $rc -eq 0 ] && { timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $SHORT > $OUT/pmc_fetch.log 2>&1 || rc=2; }
 [ $rc -eq 0 ] && { timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- python3 $SHORT > $OUT/pmc_write.log 2>&1 || rc=3; }
 [ $rc -eq 0 ] && { timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES -d $OUT/pmc_sq -o pmc -- python3 $SHORT > $OUT/pmc_sq.log 2>&1 || rc=4; }
+[ $rc -eq 0 ] && { timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM -d $OUT/pmc_mfma -o pmc -- python3 $SHORT > $OUT/pmc_mfma.log 2>&1 || rc=6; }
 [ $rc -eq 0 ] && { timeout -s KILL 300 rocprofv3 --pmc GRBM_GUI_ACTIVE -d $OUT/pmc_grbm -o pmc -- python3 $SHORT > $OUT/pmc_grbm.log 2>&1 || rc=5; }
 python3 $R/profiles/summarize.py $OUT > $OUT/summary.txt
 find $OUT -name "*.db" -delete
