@@ -236,6 +236,7 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N>1: nccl (= RCCL over xGMI, one GPU per rank); gloo only to rehearse the "
                     "multi-rank path on a box with fewer GPUs than ranks (ranks then share GPUs)")
+    ap.add_argument("--no-overlap", action="store_true", help="one step at a time on one stream (no overlap of a step's tail with the next step)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the T-RANSAC / LM / triangulation timings")
     ap.add_argument("--e2e", action="store_true", help="only run the synthetic dataset-5-shaped end-to-end geometry and print it")
     ap.add_argument("--e2e-cpu", action="store_true", help="with --e2e: also time the NumPy oracle end to end (minutes) and compare")
@@ -297,24 +298,41 @@ def main():
     last_stats = {}
     workspace = ops.eh_best_workspace(B, n)
 
-    def step():
-        # one library call: float32 bounds for all hypotheses -> candidates -> float64 re-score -> exact winners
-        (cE, iE), (cH, iH), st = ops.eh_best_native(corr, corr32, idx, thr, 3 * thr, xmax, workspace=workspace)
+    # Steps are independent blocks of hypotheses, so two are kept in flight on two streams: the short tail of a step
+    # (arg-max, leader and candidate re-scores, read-back) runs in the shadow of the next step's bulk kernel.
+    depth = 1 if args.no_overlap else 2
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    workspaces = [workspace] + [ops.eh_best_workspace(B, n) for _ in range(depth - 1)]
+    pendings = [ops.eh_best_pending() for _ in range(depth)]
+    torch.cuda.synchronize()
+
+    def finish(job):
+        (cE, iE), (cH, iH), st = ops.eh_best_collect(job)
         last_stats.update(st)
         best.copy_(torch.tensor([sharding.pack_key(cE, base + iE), sharding.pack_key(cH, base + iH)], dtype=torch.int64))
         sharding.merge_best(best)  # RCCL all-reduce(max) of the packed winners when world > 1
+
+    def run_steps(k):
+        # every step: float32 bounds for all hypotheses -> candidates -> float64 re-score -> exact winners -> merge
+        prev = None
+        for i in range(k):
+            job = ops.eh_best_submit(corr, corr32, idx, thr, 3 * thr, xmax, workspace=workspaces[i % depth], stream=streams[i % depth],
+                                     pending=pendings[i % depth])
+            if prev is not None:
+                finish(prev)
+            prev = job
+        if prev is not None:
+            finish(prev)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=key_device)

@@ -75,6 +75,19 @@ int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const i
  * Unlike the other entry points this one synchronises `stream` (it reads a few words back to decide
  * the next level). */
 int64_t sfm_eh_best_workspace_bytes(int64_t nb, int32_t n);
+/* The same step split in two, so that a caller can keep several blocks of hypotheses in flight on different
+ * streams: submit only enqueues work on `stream` (all bound levels for the usual case of at most 256 candidates
+ * per class, and one copy of the outcome into host_pending: sfm_eh_best_pending_bytes() bytes of host memory,
+ * page-locked if the call is to return before the work is done); collect waits for `stream`, reads host_pending
+ * and, only when there were more candidates than that, runs the remaining levels.  Both take the same arguments;
+ * one workspace and one host_pending per block in flight. */
+int64_t sfm_eh_best_pending_bytes(void);
+int sfm_eh_best_submit(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e,
+                       double thr_h, double xmax, double safety, int32_t loose, void* workspace, int64_t workspace_bytes,
+                       void* host_pending, void* stream);
+int sfm_eh_best_collect(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e,
+                        double thr_h, double xmax, double safety, int32_t loose, void* workspace, int64_t workspace_bytes,
+                        const void* host_pending, int64_t* result, void* stream);
 int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
                 double xmax, double safety, int32_t loose, void* workspace, int64_t workspace_bytes, int64_t* result,
                 void* stream);

@@ -924,6 +924,41 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const int32_t* __re
   if (t < 12LL * count) rows_out[t] = idx[12LL * ids[t / 12] + (t % 12)];
 }
 
+// Speculative last level: while the host has not looked at the candidate counts yet, the first kSpecCap
+// candidates of each class are already gathered (slots beyond the count repeat the class leader) ...
+constexpr int kSpecCap = 256;
+
+struct BestPending {  // what the host reads back in one copy: 8 x int64 + ids and exact counts of the speculative slots
+  BestInfo info;
+  int32_t ids[2 * kSpecCap];
+  int32_t counts[2 * kSpecCap];
+};
+
+__global__ __launch_bounds__(kBlock) void gather_spec_rows_kernel(const BestInfo* __restrict__ info, const int32_t* __restrict__ cand_e,
+                                                                  const int32_t* __restrict__ cand_h, const int32_t* __restrict__ idx,
+                                                                  int32_t* __restrict__ rows, int32_t* __restrict__ ids_out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * kSpecCap * 12) return;
+  const int slot = t / 12, cls = slot / kSpecCap, j = slot % kSpecCap;
+  const long long ncand = cls ? info->ncand_h : info->ncand_e;
+  const bool live = j < ncand;
+  const long long id = live ? (long long)(cls ? cand_h : cand_e)[j] : (cls ? info->lead_h : info->lead_e);
+  rows[t] = idx[12 * id + (t % 12)];
+  if (t % 12 == 0) ids_out[slot] = live ? (int32_t)id : -1;
+}
+
+// ... and scored exactly; this packs the outcome for the host
+__global__ __launch_bounds__(kBlock) void pack_pending_kernel(const BestInfo* __restrict__ info, const int32_t* __restrict__ ids,
+                                                              const int* __restrict__ sc_e, const int* __restrict__ sc_h,
+                                                              BestPending* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) out->info = *info;
+  if (t < 2 * kSpecCap) {
+    out->ids[t] = ids[t];
+    out->counts[t] = t < kSpecCap ? sc_e[t] : sc_h[t];
+  }
+}
+
 // keeps the candidates whose tight bound still reaches the floor (in place, unordered)
 __global__ __launch_bounds__(kBlock) void refilter_kernel(const int32_t* __restrict__ ids_in, const int* __restrict__ bound, int count, int floor,
                                                           int32_t* __restrict__ ids_out, unsigned long long* __restrict__ n_out) {
@@ -1243,6 +1278,8 @@ constexpr int kTightenAbove = 4096;  // more candidates than this are first re-b
 
 struct BestWs {
   void* corrm;
+  int32_t* spec_ids;
+  BestPending* pending;
   int *up_e, *up_h, *lead_counts, *sc_e, *sc_h;
   unsigned long long *keys, *n2;
   BestInfo* info;
@@ -1270,6 +1307,8 @@ inline size_t carve(char* base, int64_t nb, int32_t n, BestWs* w) {
   w->sc_e = (int*)take(sizeof(int) * 2 * kCandCap);
   w->sc_h = (int*)take(sizeof(int) * 2 * kCandCap);
   w->corrm = take((size_t)((n + 31) & ~31) * 40);
+  w->spec_ids = (int32_t*)take(sizeof(int32_t) * 2 * kSpecCap);
+  w->pending = (BestPending*)take(sizeof(BestPending));
   return off;
 }
 }  // namespace
@@ -1285,14 +1324,16 @@ int64_t sfm_eh_best_workspace_bytes(int64_t nb, int32_t n) {
     if (rc_ != 0) return rc_;    \
   } while (0)
 
-int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax,
-                double safety, int32_t loose, void* workspace, int64_t workspace_bytes, int64_t* result, void* stream) {
+int64_t sfm_eh_best_pending_bytes(void) { return (int64_t)sizeof(BestPending); }
+
+int sfm_eh_best_submit(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
+                       double xmax, double safety, int32_t loose, void* workspace, int64_t workspace_bytes, void* host_pending,
+                       void* stream) {
   clear_stale_error();
-  if (!corr || !corr32 || !idx || !workspace || !result || n <= 0 || nb <= 0 || (uint64_t)nb > 0x7FFFFFFFull) return SFM_EINVAL;
+  if (!corr || !corr32 || !idx || !workspace || !host_pending || n <= 0 || nb <= 0 || (uint64_t)nb > 0x7FFFFFFFull) return SFM_EINVAL;
   BestWs w;
   if (((uintptr_t)workspace & 255u) != 0 || (int64_t)carve((char*)workspace, nb, n, &w) > workspace_bytes) return SFM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  for (int i = 0; i < 8; ++i) result[i] = 0;
   // level 1: float32 bounds for every hypothesis, leaders, their exact counts, candidate lists
   if (loose == 2) {
     SFM_TRY(launch_corr_to_mfma(corr, n, w.corrm, st));
@@ -1301,27 +1342,66 @@ int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_
     SFM_TRY(launch_eh_upper(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, loose, w.up_e, w.up_h, st));
   }
   SFM_TRY(hipMemsetAsync(w.keys, 0, 256 * 3, st));  // keys, n2, info (three consecutive 256-byte slots)
-  {
-    const long long tiles = (nb + kBlock - 1) / kBlock;
-    const int ablocks = (int)(tiles < 256 ? tiles : 256);
-    argmax_kernel<<<dim3(ablocks, 1), kBlock, 0, st>>>(w.up_e, nb, 0ull, w.keys);
-    argmax_kernel<<<dim3(ablocks, 1), kBlock, 0, st>>>(w.up_h, nb, 0ull, w.keys + 1);
-    gather_leaders_kernel<<<1, 64, 0, st>>>(w.keys, idx, nb, w.lead_rows, w.info);
-    SFM_TRY(check_launch());
-    SFM_TRY(launch_eh_score(corr, n, w.lead_rows, 2, thr_e, thr_h, w.lead_counts, w.lead_counts + 2, st));
-    select_candidates_kernel<<<ablocks, kBlock, 0, st>>>(w.up_e, w.up_h, nb, w.lead_counts, w.info, w.cand_e, w.cand_h, kCandCap);
-    SFM_TRY(check_launch());
-  }
-  BestInfo info;
-  SFM_TRY(hipMemcpyAsync(&info, w.info, sizeof(info), hipMemcpyDeviceToHost, st));
+  const long long tiles = (nb + kBlock - 1) / kBlock;
+  const int ablocks = (int)(tiles < 256 ? tiles : 256);
+  argmax_kernel<<<dim3(ablocks, 1), kBlock, 0, st>>>(w.up_e, nb, 0ull, w.keys);
+  argmax_kernel<<<dim3(ablocks, 1), kBlock, 0, st>>>(w.up_h, nb, 0ull, w.keys + 1);
+  gather_leaders_kernel<<<1, 64, 0, st>>>(w.keys, idx, nb, w.lead_rows, w.info);
+  SFM_TRY(check_launch());
+  SFM_TRY(launch_eh_score(corr, n, w.lead_rows, 2, thr_e, thr_h, w.lead_counts, w.lead_counts + 2, st));
+  select_candidates_kernel<<<ablocks, kBlock, 0, st>>>(w.up_e, w.up_h, nb, w.lead_counts, w.info, w.cand_e, w.cand_h, kCandCap);
+  // speculative last level: the first kSpecCap candidates of each class are scored exactly right away, so that in
+  // the usual case (a handful of candidates) the host needs one look at the outcome and no further launch
+  gather_spec_rows_kernel<<<div_up(2 * kSpecCap * 12, kBlock), kBlock, 0, st>>>(w.info, w.cand_e, w.cand_h, idx, w.rows, w.spec_ids);
+  SFM_TRY(check_launch());
+  SFM_TRY(launch_eh_score(corr, n, w.rows, 2 * kSpecCap, thr_e, thr_h, w.sc_e, w.sc_h, st));
+  pack_pending_kernel<<<div_up(2 * kSpecCap, kBlock), kBlock, 0, st>>>(w.info, w.spec_ids, w.sc_e, w.sc_h, w.pending);
+  SFM_TRY(check_launch());
+  SFM_TRY(hipMemcpyAsync(host_pending, w.pending, sizeof(BestPending), hipMemcpyDeviceToHost, st));
+  return 0;
+}
+
+int sfm_eh_best_collect(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
+                        double xmax, double safety, int32_t loose, void* workspace, int64_t workspace_bytes, const void* host_pending,
+                        int64_t* result, void* stream) {
+  clear_stale_error();
+  if (!corr || !corr32 || !idx || !workspace || !host_pending || !result || n <= 0 || nb <= 0 || (uint64_t)nb > 0x7FFFFFFFull)
+    return SFM_EINVAL;
+  BestWs w;
+  if (((uintptr_t)workspace & 255u) != 0 || (int64_t)carve((char*)workspace, nb, n, &w) > workspace_bytes) return SFM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < 8; ++i) result[i] = 0;
   SFM_TRY(hipStreamSynchronize(st));
+  const BestPending* pend = (const BestPending*)host_pending;
+  BestInfo info = pend->info;
+  result[4] = info.ncand_e;
+  result[5] = info.ncand_h;
+  if (info.ncand_e <= kSpecCap && info.ncand_h <= kSpecCap) {
+    // every candidate was already scored exactly: first maximum = largest count, lowest id
+    for (int cls = 0; cls < 2; ++cls) {
+      const int cnt_n = (int)(cls ? info.ncand_h : info.ncand_e);
+      long long bc = -1, bi = -1;
+      for (int k = 0; k < cnt_n; ++k) {
+        const long long c = pend->counts[cls * kSpecCap + k], id = pend->ids[cls * kSpecCap + k];
+        if (c > bc || (c == bc && id < bi)) {
+          bc = c;
+          bi = id;
+        }
+      }
+      if (bi < 0) {  // cannot happen (the leader always qualifies); keep the leader's exact count
+        bc = cls ? info.floor_h : info.floor_e;
+        bi = cls ? info.lead_h : info.lead_e;
+      }
+      result[2 * cls] = bc;
+      result[2 * cls + 1] = bi;
+    }
+    result[7] = info.ncand_e + info.ncand_h;
+    return 0;
+  }
   result[0] = info.floor_e;
   result[1] = info.lead_e;
   result[2] = info.floor_h;
   result[3] = info.lead_h;
-  result[4] = info.ncand_e;
-  result[5] = info.ncand_h;
-  if (info.ncand_e <= 1 && info.ncand_h <= 1) return 0;  // each leader is the only hypothesis that can reach its own count
   if (loose && (info.ncand_e > kCandCap || info.ncand_h > kCandCap)) {
     // too many survivors of the loose bounds for the candidate lists (e.g. a scene whose best count is
     // tiny): apply the tight bounds to every hypothesis and select again with the same floors
@@ -1413,6 +1493,14 @@ int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_
   }
   result[7] = ne + nh;
   return 0;
+}
+
+int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax,
+                double safety, int32_t loose, void* workspace, int64_t workspace_bytes, int64_t* result, void* stream) {
+  static thread_local BestPending pending;  // pageable: the copy into it completes before hipMemcpyAsync returns or at the sync below
+  SFM_TRY(sfm_eh_best_submit(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, loose, workspace, workspace_bytes, &pending, stream));
+  return sfm_eh_best_collect(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, loose, workspace, workspace_bytes, &pending, result,
+                             stream);
 }
 
 int sfm_eh_models_f64(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double* F_out, double* E_out, double* H_out,

@@ -25,6 +25,11 @@ _SIGS = {
     "sfm_eh_best_workspace_bytes": (_c.c_int64, [_c.c_int64, _c.c_int32]),
     "sfm_eh_best": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int32, _P,
                                _c.c_int64, _P, _P]),
+    "sfm_eh_best_pending_bytes": (_c.c_int64, []),
+    "sfm_eh_best_submit": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int32, _P,
+                                      _c.c_int64, _P, _P]),
+    "sfm_eh_best_collect": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int32,
+                                       _P, _c.c_int64, _P, _P, _P]),
     "sfm_eh_models_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _P, _P, _P, _P]),
     "sfm_epipolar_mask_f64": (_c.c_int, [_P, _P, _c.c_int32, _c.c_double, _P, _P, _P]),
     "sfm_transfer_mask_f64": (_c.c_int, [_P, _P, _c.c_int32, _c.c_double, _P, _P, _P]),

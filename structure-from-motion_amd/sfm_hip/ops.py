@@ -123,6 +123,45 @@ def eh_best_native(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, loose=2, w
     return (int(res[0]), int(res[1])), (int(res[2]), int(res[3])), stats
 
 
+class EhBestJob:
+    """One block of hypotheses in flight: eh_best_submit enqueues all levels of the cascade on `stream` (no host
+    synchronisation), eh_best_collect waits and returns what eh_best_native returns.  Keep one workspace per job."""
+
+    def __init__(self, args, workspace, pending, stream):
+        self.args, self.workspace, self.pending, self.stream = args, workspace, pending, stream
+
+
+def eh_best_pending():
+    """Page-locked host buffer that receives the outcome of one job."""
+    torch = C.torch_cuda()
+    return torch.empty(int(C.load_library().sfm_eh_best_pending_bytes()), dtype=torch.uint8, pin_memory=True)
+
+
+def eh_best_submit(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, loose=2, workspace=None, stream=None, pending=None):
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    nb = idx.shape[0]
+    if workspace is None:
+        workspace = eh_best_workspace(nb, corr.shape[0])
+    if pending is None:
+        pending = eh_best_pending()
+    sp = C.stream_ptr() if stream is None else stream.cuda_stream
+    args = (C.dptr(corr), C.dptr(corr32), corr.shape[0], C.dptr(idx), nb, float(thr_e), float(thr_h), float(xmax), float(safety),
+            int(loose), C.dptr(workspace), workspace.numel())
+    C.check(lib.sfm_eh_best_submit(*args, pending.data_ptr(), sp))
+    job = EhBestJob(args, workspace, pending, sp)
+    job.keep = (corr, corr32, idx)  # the device buffers must outlive the job
+    return job
+
+
+def eh_best_collect(job):
+    lib = C.load_library()
+    res = np.zeros(8, np.int64)
+    C.check(lib.sfm_eh_best_collect(*job.args, job.pending.data_ptr(), C.hptr(res), job.stream))
+    stats = {"candidates_e": int(res[4]), "candidates_h": int(res[5]), "tightened": int(res[6]), "rescored_f64": int(res[7])}
+    return (int(res[0]), int(res[1])), (int(res[2]), int(res[3])), stats
+
+
 TIGHTEN_ABOVE = 4096  # candidates beyond this count go through the tight float32 bound before float64
 
 

@@ -368,3 +368,29 @@ def test_matrix_core_bounds_are_upper_bounds(ops, dev, n, B, inl, seed):
     assert int((me < ce).sum()) == 0 and int((mh < ch).sum()) == 0
     assert float((me - ce).double().mean()) <= float((ve - ce).double().mean()) * 1.2 + 0.5
     assert float((mh - ch).double().mean()) <= float((vh - ch).double().mean()) * 1.2 + 0.5
+
+
+def test_submit_collect_two_jobs_in_flight(ops, dev):
+    """sfm_eh_best_submit / _collect: two blocks of hypotheses in flight on two streams give what the blocking call gives,
+    in the usual case (few candidates, answered by the speculative level) and with thousands of candidates."""
+    import torch
+
+    for inl, n, B, seed in [(0.3, 5000, 100000, 0), (0.0, 3000, 200000, 6)]:
+        sc, x1, x2 = scene(n=n, inl=inl, pl=0.5, seed=seed)
+        corr_h = ops.pack_corr(x1, x2)
+        corr = dev(corr_h)
+        c32 = ops.corr_to_f32(corr)
+        xmax = float(np.abs(corr_h).max())
+        thr = 1.0 / sc["K"][0][0]
+        idxs = [ops.index_sets(seed + k, 0, B, n) for k in range(2)]
+        want = [ops.eh_best_native(corr, c32, i, thr, 3 * thr, xmax) for i in idxs]
+        exact = [[t.cpu().numpy() for t in ops.eh_score(corr, i, thr, 3 * thr)] for i in idxs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        jobs = [ops.eh_best_submit(corr, c32, i, thr, 3 * thr, xmax, stream=s) for i, s in zip(idxs, streams)]
+        got = [ops.eh_best_collect(j) for j in jobs]
+        for g, w, (ce, ch) in zip(got, want, exact):
+            assert g[0] == w[0] and g[1] == w[1]
+            assert g[0] == (int(ce.max()), int(np.argmax(ce))) and g[1] == (int(ch.max()), int(np.argmax(ch)))
+        if inl == 0.0:
+            assert got[0][2]["candidates_e"] + got[0][2]["candidates_h"] > 512  # beyond the speculative level
