@@ -9,7 +9,9 @@ merge of the per-rank winners by one all-reduce(max) of packed (count, index) ke
 
 Metric: hypothesis x correspondence residual evaluations per second (an E residual and an H
 residual each count as one evaluation).  Inputs (matches and index sets) are resident in HBM
-before the timed region.
+before the timed region.  Steps are independent blocks of hypotheses; two are kept in flight on
+two HIP streams (sfm_eh_best_submit / _collect), every step is collected and merged inside the
+timed region (--no-overlap runs them strictly one after the other).
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -30,7 +32,7 @@ FLOPS_PER_E_EVAL = 36  # algorithmic cost of one symmetric-epipolar residual tes
 FLOPS_PER_H_EVAL = 21  # one transfer-error residual test
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32
 PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector FP64 (half of the FP32 vector rate)
-PMC_TRAFFIC_BYTES = (2 * 26440.9 + 7812.5) * 1024  # FETCH_SIZE x2 + WRITE_SIZE of the dominant kernel, KB -> bytes
+PMC_TRAFFIC_BYTES = (2 * 26441.7 + 7812.5) * 1024  # FETCH_SIZE x2 + WRITE_SIZE of the dominant kernel, KB -> bytes
 
 
 def cpu_baseline(x1n, x2n, thr, n_matches, idx):
@@ -415,7 +417,7 @@ def main():
                 "peak": PEAK_FP32_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01i_summary.txt):
+                # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01j_summary.txt):
                 # FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE; algorithmic bytes are
                 # 48 MB of index sets + 0.5 MB of matches read, 8 MB of counts written.
                 "traffic": PMC_TRAFFIC_BYTES if (n, B) == (10000, 1000000) else None,

@@ -10,7 +10,8 @@ rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$R/bench.py --cpu-sample 0 ${BENCH_EXTRA:-}"
-SHORT="$R/bench.py --cpu-sample 0 --steps 3 --warmup 1 ${BENCH_EXTRA:-}"
+# counters are device-wide: the PMC passes run one step at a time so that a dispatch is not charged with its neighbour's traffic
+SHORT="$R/bench.py --cpu-sample 0 --steps 3 --warmup 1 --no-overlap ${BENCH_EXTRA:-}"
 rc=0
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $ARGS > $OUT/trace.log 2>&1 || rc=1
 [ $rc -eq 0 ] && { timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- python3 $SHORT > $OUT/pmc_fetch.log 2>&1 || rc=2; }

@@ -26,6 +26,9 @@ def main(d):
             for name, durs in per.items():
                 big = [x for x in durs if x > 0.25 * max(durs)]
                 print(f"{name:80s} | n={len(durs)} | full-size launches: " + " ".join(f"{x:.0f}" for x in big[:24]))
+                tail = big[-20:]
+                print(f"{'':80s} |   last {len(tail)} full-size launches (bench times these one at a time with events; earlier ones may "
+                      f"overlap with another stream's launch): avg {sum(tail) / len(tail):.1f} us")
         except Exception as e:  # schema differences between rocprofv3 versions
             print("  (per-dispatch listing unavailable:", e, ")")
     for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
