@@ -159,6 +159,42 @@ def secondary_measurements(torch, ops, _capi, synthetic, seed):
     return out
 
 
+def seed_sweep(torch, ops, _capi, synthetic, orc, n, B):
+    """The headline step on scenes generated with seeds 0..4 (two steps in flight, 6 timed steps each): evals/s per
+    seed and their median."""
+    rates, winners = [], []
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ws = [ops.eh_best_workspace(B, n) for _ in range(2)]
+    pend = [ops.eh_best_pending() for _ in range(2)]
+    for seed in range(5):
+        sc = synthetic.two_view_scene(n=n, inlier_ratio=0.3, planar_ratio=0.5, seed=seed)
+        thr = 1.0 / sc["K"][0][0]
+        corr_h = ops.pack_corr(orc.normalize_K(sc["K"], sc["x1"]), orc.normalize_K(sc["K"], sc["x2"]))
+        corr = _capi.dev(corr_h)
+        corr32 = ops.corr_to_f32(corr)
+        xmax = float(np.abs(corr_h).max())
+        idx = ops.index_sets(seed, 0, B, n)
+        torch.cuda.synchronize()
+
+        def run(k):
+            prev, out = None, None
+            for i in range(k):
+                job = ops.eh_best_submit(corr, corr32, idx, thr, 3 * thr, xmax, workspace=ws[i % 2], stream=streams[i % 2], pending=pend[i % 2])
+                if prev is not None:
+                    out = ops.eh_best_collect(prev)
+                prev = job
+            return ops.eh_best_collect(prev) if prev is not None else out
+
+        run(3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wE, wH, _ = run(6)
+        torch.cuda.synchronize()
+        rates.append(2.0 * n * B * 6 / (time.perf_counter() - t0))
+        winners.append([list(wE), list(wH)])
+    return {"seeds": [0, 1, 2, 3, 4], "evals_per_s": rates, "median_evals_per_s": float(np.median(rates)), "winners_E_H": winners}
+
+
 def sweep(torch, ops, _capi, synthetic, orc, seed):
     """Throughput of the two-tier E+H scoring step over match-set sizes (one GPU)."""
     rows = []
@@ -471,6 +507,7 @@ def main():
         if world == 1 and not args.no_secondary:
             try:  # the headline line must print even if a side measurement fails
                 out["secondary"] = secondary_measurements(torch, ops, _capi, synthetic, args.seed)
+                out["secondary"]["seed_sweep"] = seed_sweep(torch, ops, _capi, synthetic, orc, n, B)
             except Exception as e:  # noqa: BLE001
                 out["secondary"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))

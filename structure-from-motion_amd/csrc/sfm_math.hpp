@@ -189,14 +189,6 @@ SFM_FN T det3(const T (&M)[3][3]) {
          M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
 }
 
-template <typename T>
-SFM_FN void matmul3(const T (&A)[3][3], const T (&B)[3][3], T (&C)[3][3]) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) C[i][j] = fma(A[i][0], B[0][j], fma(A[i][1], B[1][j], A[i][2] * B[2][j]));
-}
-
 // ---------------------------------------------------------------------------------------
 // Minimal solvers.  Correspondences are (x1, y1, x2, y2) with both third coordinates 1.
 // ---------------------------------------------------------------------------------------
