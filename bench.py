@@ -75,13 +75,21 @@ def secondary_measurements(torch, ops, _capi, synthetic, seed):
     pts = torch.cat([ops.pack_points(_capi.dev(c["R"].ravel()), _capi.dev(c["X"]), _capi.dev(c["x_norm"])) for c in cams])
     idx = _capi.dev(rng.integers(0, m, size=(ncam, B, 2)), np.int32)
     thr = 4.0 / K[0][0]
-    ops.t_ransac(pts, [m] * ncam, idx, thr)
-    torch.cuda.synchronize()
     reps = 3
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ops.t_ransac(pts, [m] * ncam, idx, thr, mixed=True)
+    torch.cuda.synchronize()
     a.record()
     for _ in range(reps):
-        best, T, counts = ops.t_ransac(pts, [m] * ncam, idx, thr)
+        best_m, T_m, counts_m = ops.t_ransac(pts, [m] * ncam, idx, thr, mixed=True)
+    b.record()
+    torch.cuda.synchronize()
+    ms_mixed = a.elapsed_time(b) / reps
+    ops.t_ransac(pts, [m] * ncam, idx, thr, mixed=False)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        best, T, counts = ops.t_ransac(pts, [m] * ncam, idx, thr, mixed=False)
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / reps
@@ -100,6 +108,9 @@ def secondary_measurements(torch, ops, _capi, synthetic, seed):
     ms2 = (time.perf_counter() - t0) / reps * 1e3
     out["t_ransac"] = {
         "workload": f"{ncam} cameras x {m} 2D-3D correspondences x {B} hypotheses, one launch",
+        "mixed_ms": ms_mixed,
+        "mixed_evals_per_s": ncam * float(m) * B / (ms_mixed * 1e-3),
+        "mixed_counts_identical_to_f64": bool(torch.equal(counts_m, counts) and torch.equal(best_m, best)),
         "f64_ms": ms,
         "f64_evals_per_s": ncam * float(m) * B / (ms * 1e-3),
         "two_tier_ms": ms2,

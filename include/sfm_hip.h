@@ -212,6 +212,15 @@ int sfm_corr_to_mfma(const double* corr, int32_t n, void* corrm, void* stream);
 int sfm_eh_upper_mfma_f32(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e,
                           double thr_h, double xmax, double safety, int32_t* up_e, int32_t* up_h, void* stream);
 
+/* sfm_t_ransac_f64 with the bulk of the residual tests on the bf16 matrix cores + float32 and IDENTICAL counts:
+ * dx, dy and thr*pz of src/estimate_translation.py:123-127 are bilinear in (hypothesis, correspondence) and come from
+ * one MFMA each per 32 x 32 pairs (three-piece splits of the float64 values); a pair whose float32 value lies within
+ * the rigorous error band of the threshold (about one in 10^6) is re-evaluated in float64 inside the kernel.
+ * workspace: device scratch of sfm_t_ransac_mixed_workspace_bytes(cam_off, ncam) bytes, 256-byte aligned. */
+int64_t sfm_t_ransac_mixed_workspace_bytes(const int64_t* cam_off, int32_t ncam);
+int sfm_t_ransac_mixed(const double* pts, const int64_t* cam_off, int32_t ncam, const int32_t* idx, int64_t nb, double thr,
+                       void* workspace, int64_t workspace_bytes, int32_t* counts, uint64_t* best, double* T_best, void* stream);
+
 /* ---- descriptor matching (feature front-end next to the path) ------------------------------
  * Replaces `cv2.BFMatcher().knnMatch(desc_query, desc_train, k=2)` followed by the ratio test
  * `m.distance < ratio * n.distance` (src/extract_sift.py:117-123 with ratio 0.4,

@@ -824,6 +824,195 @@ __global__ __launch_bounds__(kBlock) void t_upper_kernel(const double* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Translation RANSAC with EXACT float64 counts at matrix-core + float32 cost.
+//   dx = (rx - u rz) + tx - u tz,  dy = (ry - v rz) + ty - v tz,  q = thr (rz + tz)
+// are bilinear in (hypothesis, correspondence), so each is one bf16 MFMA per 32 x 32 pairs from
+// three-piece splits (same expansion and error bound as in eh_upper_mfma_kernel); the float32 value
+// d = dx^2 + dy^2 - q^2 then decides the pair by its sign unless |d| <= delta, the rigorous bound of
+// its distance from the float64 value near the threshold: with r = |(dx, dy)| and e the bound of
+// |r_c - r| + |q_c - q|, a pair with |r - |q|| > e is decided correctly by the sign of r_c - |q_c|,
+// and any other pair has |d_c| <= 4 e |q_c| + 4 e^2 (+ float32 rounding of d_c) = delta.  Pairs inside
+// the band (about one in 10^6) are re-evaluated with the float64 test of t_score_kernel on the spot,
+// so the counts are identical to t_score_kernel's for every hypothesis.
+// ---------------------------------------------------------------------------------------
+struct CamPad {
+  int64_t poff[kMaxCams + 1];  // offsets of the cameras in the padded (multiple of 32) point numbering
+};
+
+__device__ __forceinline__ void pack16(const unsigned (&e)[16], uint4& lo, uint4& hi) {
+  lo = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+  hi = make_uint4(e[8] | (e[9] << 16), e[10] | (e[11] << 16), e[12] | (e[13] << 16), e[14] | (e[15] << 16));
+}
+
+// operand vector (lead, mid, bil): k 0..2 = pieces of `lead` (or ones), k 3..5 = pieces of `mid` (or ones),
+// k 6..11 = the six-term pattern of `bil` in model or match order; unused entries are zero.
+__device__ __forceinline__ void pack_t_vector(bool lead_ones, double lead, bool mid_ones, double mid, bool has_bil, double bil, bool model_order,
+                                              uint4& lo, uint4& hi) {
+  unsigned e[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) e[i] = 0;
+  unsigned p[3];
+  if (lead_ones) {
+    e[0] = e[1] = e[2] = 0x3F80u;
+  } else {
+    split3_bf16(lead, p);
+    e[0] = p[0]; e[1] = p[1]; e[2] = p[2];
+  }
+  if (mid_ones) {
+    e[3] = e[4] = e[5] = 0x3F80u;
+  } else {
+    split3_bf16(mid, p);
+    e[3] = p[0]; e[4] = p[1]; e[5] = p[2];
+  }
+  if (has_bil) {
+    split3_bf16(bil, p);
+    if (model_order) {
+      e[6] = p[0]; e[7] = p[0]; e[8] = p[1]; e[9] = p[0]; e[10] = p[2]; e[11] = p[1];
+    } else {
+      e[6] = p[0]; e[7] = p[1]; e[8] = p[0]; e[9] = p[2]; e[10] = p[0]; e[11] = p[1];
+    }
+  }
+  pack16(e, lo, hi);
+}
+
+__device__ __forceinline__ unsigned f32_up_bits(double v) { return __float_as_uint(round_up_f32(v)); }
+
+// grid = (padded point blocks, cameras).  pieces[P][3][2]: the match-side vectors of dx, dy and q;
+// maxima[cam][4] = max |rx - u rz|, |ry - v rz|, |rz|, max(|u|, |v|) as float32 bit patterns (rounded up).
+__global__ __launch_bounds__(kBlock) void t_prep_mfma_kernel(const double* __restrict__ pts_all, CamOffsets offs, CamPad pads, double thr,
+                                                             uint4* __restrict__ pieces, unsigned* __restrict__ maxima) {
+  const int cam = blockIdx.y;
+  const int m = (int)(offs.off[cam + 1] - offs.off[cam]);
+  const int mp = (int)(pads.poff[cam + 1] - pads.poff[cam]);
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned mx[4] = {0u, 0u, 0u, 0u};
+  if (j < mp) {
+    uint4* out = pieces + 6 * (pads.poff[cam] + j);
+    if (j < m) {
+      const double* p = pts_all + 6 * (offs.off[cam] + j);
+      const double rx = p[0], ry = p[1], rz = p[2], u = p[3], v = p[4];
+      const double a = fma(-u, rz, rx), b = fma(-v, rz, ry);
+      pack_t_vector(false, a, true, 0.0, true, -u, false, out[0], out[1]);
+      pack_t_vector(false, b, true, 0.0, true, -v, false, out[2], out[3]);
+      pack_t_vector(false, thr * rz, true, 0.0, false, 0.0, false, out[4], out[5]);
+      mx[0] = f32_up_bits(fabs(a));
+      mx[1] = f32_up_bits(fabs(b));
+      mx[2] = f32_up_bits(fabs(rz));
+      mx[3] = f32_up_bits(fmax(fabs(u), fabs(v)));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) out[i] = make_uint4(0, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx[c] = max(mx[c], (unsigned)__shfl_xor((int)mx[c], o));  // non-negative floats order like their bits
+    if ((threadIdx.x & 63) == 0 && mx[c]) atomicMax(maxima + 4 * cam + c, mx[c]);
+  }
+}
+
+// grid = (hypothesis tiles, cameras, splits over the camera's tiles of 32 correspondences)
+__global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* __restrict__ pts_all, const uint4* __restrict__ pieces,
+                                                                 const unsigned* __restrict__ maxima, CamOffsets offs, CamPad pads,
+                                                                 const int32_t* __restrict__ idx, long long nb, double thr2,
+                                                                 int* __restrict__ counts, int tiles_per_split, int use_atomics) {
+  __shared__ uint4 bstage[kBlock / 64][64][3][2];
+  __shared__ double tstage[kBlock / 64][64][3];
+  const int cam = blockIdx.y;
+  const double* __restrict__ pts = pts_all + 6 * offs.off[cam];
+  const uint4* __restrict__ pc = pieces + 6 * pads.poff[cam];
+  const int m = (int)(offs.off[cam + 1] - offs.off[cam]);
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long hyp = gid < nb ? gid : nb - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  float c1_own, c0_own;
+  {
+    const int32_t* pair = idx + 2 * ((long long)cam * nb + hyp);
+    double T[3];
+    {
+      double x[2][3], r[2][3];
+      load_t_sample(pts, pair, x, r);
+      solve_T2<double>(x, r, pair[0] == pair[1], T);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tstage[wave][lane][i] = T[i];
+    const double tmax = fmax(fabs(T[0]), fmax(fabs(T[1]), fabs(T[2])));
+    const bool usable = tmax < 1.0e6;  // false for NaN / infinite / absurd translations: those are scored entirely in float64
+    const double thr = sqrt(thr2);
+    const double amax = __uint_as_float(maxima[4 * cam]), bmax = __uint_as_float(maxima[4 * cam + 1]);
+    const double zmax = __uint_as_float(maxima[4 * cam + 2]), uvmax = __uint_as_float(maxima[4 * cam + 3]);
+    const double Rx = amax + fabs(T[0]) + uvmax * fabs(T[2]), Ry = bmax + fabs(T[1]) + uvmax * fabs(T[2]);
+    const double Rq = thr * (zmax + fabs(T[2]));
+    const double e = 2.0 * kEpsMfma * (Rx + Ry + Rq);  // bound of |r_c - r| + |q_c - q|, doubled
+    c1_own = usable ? round_up_f32(4.0 * e + 13.0 * kEps32 * Rq * 1.001) : 0.0f;
+    c0_own = usable ? round_up_f32(4.1 * e * e) : __builtin_inff();
+    const double tx = usable ? T[0] : 0.0, ty = usable ? T[1] : 0.0, tz = usable ? T[2] : 0.0;
+    pack_t_vector(true, 0.0, false, tx, true, tz, true, bstage[wave][lane][0][0], bstage[wave][lane][0][1]);
+    pack_t_vector(true, 0.0, false, ty, true, tz, true, bstage[wave][lane][1][0], bstage[wave][lane][1][1]);
+    pack_t_vector(true, 0.0, false, thr * tz, false, 0.0, true, bstage[wave][lane][2][0], bstage[wave][lane][2][1]);
+  }
+  __syncthreads();
+  bf16x8 B[2][3];
+  float c1[2], c0[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+#pragma unroll
+    for (int v = 0; v < 3; ++v) B[k][v] = as_bf16x8(bstage[wave][32 * k + col][v][half]);
+    c1[k] = __shfl(c1_own, 32 * k + col);
+    c0[k] = __shfl(c0_own, 32 * k + col);
+  }
+  const int apos = 16 * ((col >> 2) & 1) + (col & 3) + 4 * (col >> 3);  // see eh_upper_mfma_kernel
+  const int ntiles = (m + 31) / 32;
+  const int t0 = blockIdx.z * tiles_per_split;
+  const int t1 = min(ntiles, t0 + tiles_per_split);
+  int cnt[2] = {0, 0};
+  const f32x16 zero = {0};
+  for (int t = t0; t < t1; ++t) {
+    const uint4* src = pc + 6 * (t * 32 + apos) + half;
+    const bf16x8 Ax = as_bf16x8(src[0]), Ay = as_bf16x8(src[2]), Aq = as_bf16x8(src[4]);
+    const int nv = min(16, max(0, m - (t * 32 + 16 * half)));
+    const unsigned vmask = (0xFFFFu << (16 - nv)) & 0xFFFFu;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const f32x16 dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ax, B[k][0], zero, 0, 0, 0);
+      const f32x16 dy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay, B[k][1], zero, 0, 0, 0);
+      const f32x16 q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq, B[k][2], zero, 0, 0, 0);
+      unsigned hneg = 0, hamb = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float d = fma(-q[i], q[i], fma(dy[i], dy[i], dx[i] * dx[i]));  // < 0 <=> inlier
+        hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d), 31);
+        const float a = fabsf(d) - fma(c1[k], fabsf(q[i]), c0[k]);  // < 0 <=> the float32 sign is not trusted
+        hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(a), 31);
+      }
+      unsigned amb = hamb & vmask;
+      cnt[k] += __popc(hneg & vmask & ~amb);
+      if (amb) {
+        const double* T = tstage[wave][32 * k + col];
+        const double T0 = T[0], T1 = T[1], T2 = T[2];
+        while (amb) {
+          const int b = __ffs((int)amb) - 1;  // bit 15-i of a history is correspondence 16*half + i of the tile
+          amb &= amb - 1;
+          const double* p = pts + 6LL * (t * 32 + 16 * half + 15 - b);
+          cnt[k] += reprojection_inlier<double>(T0, T1, T2, p[0], p[1], p[2], p[3], p[4], thr2) ? 1 : 0;
+        }
+      }
+    }
+  }
+  const int s0 = cnt[0] + __shfl_xor(cnt[0], 32), s1 = cnt[1] + __shfl_xor(cnt[1], 32);
+  const int out = half ? s1 : s0;  // lane L reports hypothesis L = 32*half + col
+  if (gid < nb) {
+    int* dst = counts + (long long)cam * nb + gid;
+    if (use_atomics)
+      atomicAdd(dst, out);
+    else
+      *dst = out;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void pts_to_f32_kernel(const double* __restrict__ pts, long long m, float* __restrict__ pts32) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
@@ -1640,6 +1829,64 @@ int sfm_t_ransac_f64(const double* pts, const int64_t* cam_off, int32_t ncam, co
   argmax_kernel<<<dim3(ablocks, ncam), kBlock, 0, st>>>(counts, nb, 0ull, (unsigned long long*)best);
   rc = check_launch();
   if (rc) return rc;
+  t_winner_kernel<<<ncam, 64, 0, st>>>(pts, offs, idx, nb, (const unsigned long long*)best, T_best);
+  return check_launch();
+}
+
+static int fill_pads(const CamOffsets& offs, int32_t ncam, CamPad* pads) {
+  pads->poff[0] = 0;
+  for (int c = 0; c < ncam; ++c) {
+    const int64_t m = offs.off[c + 1] - offs.off[c];
+    pads->poff[c + 1] = pads->poff[c] + ((m + 31) & ~(int64_t)31);
+  }
+  return 0;
+}
+
+int64_t sfm_t_ransac_mixed_workspace_bytes(const int64_t* cam_off, int32_t ncam) {
+  CamOffsets offs;
+  if (fill_offsets(cam_off, ncam, &offs)) return -1;
+  CamPad pads;
+  fill_pads(offs, ncam, &pads);
+  return 1024 + pads.poff[ncam] * 96;
+}
+
+int sfm_t_ransac_mixed(const double* pts, const int64_t* cam_off, int32_t ncam, const int32_t* idx, int64_t nb, double thr, void* workspace,
+                       int64_t workspace_bytes, int32_t* counts, uint64_t* best, double* T_best, void* stream) {
+  clear_stale_error();
+  if (!pts || !idx || !counts || !best || !T_best || !workspace || nb <= 0 || !(thr > 0.0)) return SFM_EINVAL;
+  if (((uintptr_t)workspace & 255u) != 0) return SFM_EINVAL;
+  CamOffsets offs;
+  int rc = fill_offsets(cam_off, ncam, &offs);
+  if (rc) return rc;
+  CamPad pads;
+  fill_pads(offs, ncam, &pads);
+  if (workspace_bytes < 1024 + pads.poff[ncam] * 96) return SFM_EINVAL;  // 1024-byte header: 4 maxima per camera
+  int mmax = 0;
+  for (int c = 0; c < ncam; ++c) {
+    const int m = (int)(offs.off[c + 1] - offs.off[c]);
+    if (m <= 0) return SFM_EINVAL;
+    mmax = m > mmax ? m : mmax;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  unsigned* maxima = (unsigned*)workspace;
+  uint4* pieces = (uint4*)((char*)workspace + 1024);
+  const long long tiles = (nb + kBlock - 1) / kBlock;
+  if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
+  const int ptiles = (mmax + 31) / 32;
+  int splits = choose_splits(tiles * ncam, mmax);
+  if (splits > ptiles) splits = ptiles;
+  const int tps = div_up(ptiles, splits);
+  SFM_TRY(hipMemsetAsync(maxima, 0, 1024, st));
+  if (splits > 1) SFM_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * nb * ncam, st));
+  SFM_TRY(hipMemsetAsync(best, 0, sizeof(uint64_t) * ncam, st));
+  t_prep_mfma_kernel<<<dim3(div_up(ptiles * 32, kBlock), ncam), kBlock, 0, st>>>(pts, offs, pads, thr, pieces, maxima);
+  SFM_TRY(check_launch());
+  t_score_mfma_kernel<<<dim3((unsigned)tiles, ncam, splits), kBlock, 0, st>>>(pts, pieces, maxima, offs, pads, idx, nb, thr * thr, counts, tps,
+                                                                              splits > 1);
+  SFM_TRY(check_launch());
+  const int ablocks = (int)(tiles < 256 ? tiles : 256);
+  argmax_kernel<<<dim3(ablocks, ncam), kBlock, 0, st>>>(counts, nb, 0ull, (unsigned long long*)best);
+  SFM_TRY(check_launch());
   t_winner_kernel<<<ncam, 64, 0, st>>>(pts, offs, idx, nb, (const unsigned long long*)best, T_best);
   return check_launch();
 }

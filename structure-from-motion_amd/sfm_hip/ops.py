@@ -319,8 +319,10 @@ def _offsets(cam_sizes):
     return off
 
 
-def t_ransac(pts, cam_sizes, idx, thr):
-    """pts: float64 [sum M][6]; idx: int32 [ncam][B][2] -> (best uint64->int64 view [ncam], T_best [ncam][3], counts [ncam][B])."""
+def t_ransac(pts, cam_sizes, idx, thr, mixed=True, workspace=None):
+    """pts: float64 [sum M][6]; idx: int32 [ncam][B][2] -> (best uint64->int64 view [ncam], T_best [ncam][3], counts [ncam][B]).
+    mixed=True: the residual tests run on the matrix cores + float32 with a float64 re-evaluation of the pairs inside the
+    error band (identical counts, about 2x faster); mixed=False: every test in float64."""
     torch = C.torch_cuda()
     lib = C.load_library()
     ncam, nb = idx.shape[0], idx.shape[1]
@@ -328,7 +330,14 @@ def t_ransac(pts, cam_sizes, idx, thr):
     counts = _empty((ncam, nb), torch.int32)
     best = _empty((ncam,), torch.int64)
     T = _empty((ncam, 3), torch.float64)
-    C.check(lib.sfm_t_ransac_f64(C.dptr(pts), C.hptr(off), ncam, C.dptr(idx), nb, float(thr), C.dptr(counts), C.dptr(best), C.dptr(T), C.stream_ptr()))
+    if mixed:
+        ws_bytes = int(lib.sfm_t_ransac_mixed_workspace_bytes(C.hptr(off), ncam))
+        ws = workspace if workspace is not None else _empty((ws_bytes,), torch.uint8)
+        C.check(lib.sfm_t_ransac_mixed(C.dptr(pts), C.hptr(off), ncam, C.dptr(idx), nb, float(thr), C.dptr(ws), ws.numel(), C.dptr(counts),
+                                       C.dptr(best), C.dptr(T), C.stream_ptr()))
+    else:
+        C.check(lib.sfm_t_ransac_f64(C.dptr(pts), C.hptr(off), ncam, C.dptr(idx), nb, float(thr), C.dptr(counts), C.dptr(best), C.dptr(T),
+                                     C.stream_ptr()))
     return best, T, counts
 
 

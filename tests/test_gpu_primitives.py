@@ -394,3 +394,50 @@ def test_submit_collect_two_jobs_in_flight(ops, dev):
             assert g[0] == (int(ce.max()), int(np.argmax(ce))) and g[1] == (int(ch.max()), int(np.argmax(ch)))
         if inl == 0.0:
             assert got[0][2]["candidates_e"] + got[0][2]["candidates_h"] > 512  # beyond the speculative level
+
+
+def test_mixed_translation_ransac_counts_are_identical_to_float64(ops, dev):
+    """sfm_t_ransac_mixed (matrix cores + float32, float64 inside the error band) against sfm_t_ransac_f64: every count of
+    every hypothesis, the winner and its T; cameras of ragged sizes, duplicated sample indices, correspondences placed
+    on and next to the threshold circle, and a degenerate camera whose samples give non-finite translations."""
+    import torch
+
+    K = synthetic.K_DATASET5
+    thr = 4.0 / K[0][0]
+    rng = np.random.default_rng(7)
+    sizes = [5000, 33, 1, 777, 2048]
+    cams = [synthetic.resection_scene(m=max(s, 2), outlier_ratio=0.5, seed=40 + i) for i, s in enumerate(sizes)]
+    packs = []
+    for c, s in zip(cams, sizes):
+        packs.append(ops.pack_points(dev(c["R"].ravel()), dev(c["X"]), dev(c["x_norm"]))[:s].contiguous())
+    # adversarial camera: projections placed at distance thr * (1 + k * 1e-7) around the true reprojection
+    c = synthetic.resection_scene(m=4000, outlier_ratio=0.0, seed=99)
+    p = ops.pack_points(dev(c["R"].ravel()), dev(c["X"]), dev(c["x_norm"])).cpu().numpy()
+    T = c["T_true"]
+    proj = (p[:, :3] + T)
+    uv = proj[:, :2] / proj[:, 2:3]
+    ang = rng.uniform(0, 2 * np.pi, 4000)
+    k = rng.integers(-40, 41, 4000)
+    rad = thr * (1.0 + k * 1e-7)
+    p[:, 3] = uv[:, 0] + rad * np.cos(ang)
+    p[:, 4] = uv[:, 1] + rad * np.sin(ang)
+    p[:2, 3:5] = uv[:2]  # two exact correspondences, so that the sample (0, 1) reproduces T_true
+    packs.append(dev(p))
+    sizes.append(4000)
+    # degenerate camera: all points identical -> singular 2-point systems
+    q = np.tile(p[:1], (64, 1))
+    packs.append(dev(q))
+    sizes.append(64)
+    pts = torch.cat(packs)
+    B = 5000
+    idx_h = np.stack([rng.integers(0, s, size=(B, 2)) for s in sizes]).astype(np.int32)
+    idx_h[:, :50, 1] = idx_h[:, :50, 0]  # duplicated indices
+    idx_h[5, 0] = (0, 1)
+    idx = dev(idx_h)
+    b64, T64, c64 = ops.t_ransac(pts, sizes, idx, thr, mixed=False)
+    bmx, Tmx, cmx = ops.t_ransac(pts, sizes, idx, thr, mixed=True)
+    assert torch.equal(c64, cmx)
+    assert torch.equal(b64, bmx)
+    assert np.array_equal(T64.cpu().numpy(), Tmx.cpu().numpy(), equal_nan=True)
+    assert int(c64[5, 0]) >= 2  # the adversarial camera really has points on both sides of the circle
+    assert 100 < int(c64[5, 0]) < 3900
