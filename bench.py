@@ -475,7 +475,7 @@ def main():
                 "algorithmic cost of the reference's tests (36 flops per E residual + 21 per H residual) and is priced against "
                 "the float32 vector peak, which bounds the part that is not GEMM shaped; the kernel reaches the exact winner with "
                 "cheaper implied tests, moves the two 3x3 products (24 of its 43 flops per pair) to the matrix cores and "
-                "executes 14 vector instructions per pair (see executed_valu_tflops). profiles/microbench/valu_rates measures "
+                "executes 13 vector instructions per pair (see executed_valu_tflops). profiles/microbench/valu_rates measures "
                 "131.8 TFLOP/s for a pure v_fma_f32 stream on this chip",
                 "executed_valu_tflops": 19.0 * B * n / (kern_ms * 1e-3) / 1e12,
                 # frac can exceed 1 against the vector peak alone because 24 of the 57 algorithmic flops per pair run on the
@@ -483,7 +483,7 @@ def main():
                 # (E x1, E^T x2, H x1 = 32 flops per pair) hidden entirely behind the vector work, the other 25 flops at the
                 # float32 vector peak.
                 "combined_ceiling": {"peak": PEAK_FP32_VALU_TFLOPS * 57.0 / 25.0, "frac": achieved / (PEAK_FP32_VALU_TFLOPS * 57.0 / 25.0),
-                                     "valu_issue_frac_at_2p4GHz": 14.0 * B * n / 64 / 1024 / (kern_ms * 1e-3) / 1.2e9,
+                                     "valu_issue_frac_at_2p4GHz": 13.0 * B * n / 64 / 1024 / (kern_ms * 1e-3) / 1.2e9,
                                      "mfma_busy_frac_at_2p4GHz": 6.0 * B * n / 1024 / 1024 * 32 / 2.4e9 / (kern_ms * 1e-3)},
                 "loose_valu_kernel": {"kernel": "eh_upper_kernel<true>", "kernel_ms": loose_valu_ms,
                                       "achieved": flops_per_launch / (loose_valu_ms * 1e-3) / 1e12,

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void eh_upper_kernel(const double4* __restr
 // coordinate one row of the product is a K = 6 + 6 + 3 = 15 contraction = ONE
 // v_mfma_f32_32x32x16_bf16 per 32 matches x 32 hypotheses, a quarter of the VALU time of the
 // two fmas it replaces.  The VALU keeps only what is not GEMM shaped (s = l.x2, |l|^2, the
-// box test): 14 instead of 26 instructions per pair, all on VGPR operands.
+// box test): 13 instead of 26 instructions per pair, all on VGPR operands.
 //
 // A wave solves 64 hypotheses (one per lane, float64, as everywhere else), publishes their
 // piece vectors through LDS and then owns two column blocks of 32 hypotheses; in the 32x32
