@@ -101,12 +101,19 @@ def check(code):
         raise SfmHipError(f"libsfm_hip call failed with code {code}: {msg}")
 
 
-def torch_cuda():
-    import torch
+_torch = None
 
-    if not torch.cuda.is_available():
-        raise SfmHipError("no GPU visible: the HIP path needs an MI355X and has no CPU fallback")
-    return torch
+
+def torch_cuda():
+    """torch, after checking once that a GPU is visible (there is no CPU fallback)."""
+    global _torch
+    if _torch is None:
+        import torch
+
+        if not torch.cuda.is_available():
+            raise SfmHipError("no GPU visible: the HIP path needs an MI355X and has no CPU fallback")
+        _torch = torch
+    return _torch
 
 
 def stream_ptr():
