@@ -221,6 +221,21 @@ int64_t sfm_t_ransac_mixed_workspace_bytes(const int64_t* cam_off, int32_t ncam)
 int sfm_t_ransac_mixed(const double* pts, const int64_t* cam_off, int32_t ncam, const int32_t* idx, int64_t nb, double thr,
                        void* workspace, int64_t workspace_bytes, int32_t* counts, uint64_t* best, double* T_best, void* stream);
 
+/* Record events of the E/H loop as ONE call each (launch-latency bound work: a handful of small kernels and one
+ * read-back instead of a host round trip per step).  row: HOST int32[12], the index set of the recording iteration;
+ * scratch: device double[sfm_record_scratch_doubles()]; host_out: host double[same size]; both calls synchronise.
+ * sfm_e_record_f64 = src/ransac_algorithm.py:105-113: E of the sample, its inlier mask over all matches (mask, device
+ * uint8[n]) and essential_to_RT over ALL matches; host_out: E at 0..8, the four candidate [R|t] at 18..65 (row-major
+ * 3x4 each), their chirality counts as int32[4] at double slot 66, the mask count as int32 at slot 68.
+ * sfm_h_record_f64 = :121-147: H of the sample, homography_to_RT, and for each of its two solutions the epipolar
+ * mask of E = [t]x R (mask_a / mask_b) and essential_to_RT over the masked matches; host_out additionally: H at 9..17,
+ * the homography_to_RT output at 70..112, the second solution's candidates at 113..160, counts at 161, mask count at 163. */
+int64_t sfm_record_scratch_doubles(void);
+int sfm_e_record_f64(const double* corr, int32_t n, const int32_t* row, double thr, uint8_t* mask, double* scratch,
+                     double* host_out, void* stream);
+int sfm_h_record_f64(const double* corr, int32_t n, const int32_t* row, double thr, uint8_t* mask_a, uint8_t* mask_b,
+                     double* scratch, double* host_out, void* stream);
+
 /* ---- descriptor matching (feature front-end next to the path) ------------------------------
  * Replaces `cv2.BFMatcher().knnMatch(desc_query, desc_train, k=2)` followed by the ratio test
  * `m.distance < ratio * n.distance` (src/extract_sift.py:117-123 with ratio 0.4,

@@ -557,6 +557,26 @@ __device__ __forceinline__ int block_count(bool flag) {
   return total;  // valid in thread 0
 }
 
+// models of ONE hypothesis whose index row arrives as a kernel argument (record events of the replay)
+struct RowArg {
+  int32_t v[12];
+};
+
+__global__ void models_from_row_kernel(const double4* __restrict__ corr, RowArg row, double* __restrict__ E_out, double* __restrict__ H_out) {
+  double E[9], H[9];
+  double p8[8][4], p4[4][4];
+  gather_samples<double>(corr, row.v, p8, p4);
+  solve_E8<double>(p8, E);
+  solve_H4<double>(p4, H);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      E_out[i] = E[i];
+      H_out[i] = H[i];
+    }
+  }
+}
+
 template <bool kEpipolar>
 __global__ __launch_bounds__(kBlock) void mask_kernel(const double* __restrict__ M, const double4* __restrict__ corr, int n, double thr_arg,
                                                       uint8_t* __restrict__ mask, int* __restrict__ count) {
@@ -1765,6 +1785,65 @@ int sfm_homography_to_rt_f64(const double* H, const double* corr, int32_t n, dou
   if (!H || !corr || !out || n < 0) return SFM_EINVAL;
   homography_to_rt_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(H, (const double4*)corr, n, out);
   return check_launch();
+}
+
+// ---- record events of the E/H replay as one call each -----------------------------------
+// scratch layout (doubles): E 0..8, H 9..17, P2s 18..65, rt 70..112, P2s of the second solution 113..160;
+// (int32) chirality counts at double slots 66 and 161, mask counts at 68 and 163.
+namespace {
+constexpr int kRecE = 0, kRecH = 9, kRecP = 18, kRecCnt = 66, kRecMaskCnt = 68, kRecRt = 70, kRecP2 = 113, kRecCnt2 = 161, kRecMaskCnt2 = 163;
+constexpr int kRecDoubles = 256;
+}  // namespace
+
+int64_t sfm_record_scratch_doubles(void) { return kRecDoubles; }
+
+int sfm_e_record_f64(const double* corr, int32_t n, const int32_t* row, double thr, uint8_t* mask, double* scratch, double* host_out,
+                     void* stream) {
+  clear_stale_error();
+  if (!corr || !row || !mask || !scratch || !host_out || n <= 0) return SFM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  RowArg r;
+  for (int i = 0; i < 12; ++i) {
+    if (row[i] < 0 || row[i] >= n) return SFM_EINVAL;
+    r.v[i] = row[i];
+  }
+  SFM_TRY(hipMemsetAsync(scratch + kRecCnt, 0, 4 * sizeof(double), st));
+  models_from_row_kernel<<<1, 64, 0, st>>>((const double4*)corr, r, scratch + kRecE, scratch + kRecH);
+  mask_kernel<true><<<div_up(n, kBlock), kBlock, 0, st>>>(scratch + kRecE, (const double4*)corr, n, 2.0 * thr * thr, mask,
+                                                        (int32_t*)(scratch + kRecMaskCnt));
+  essential_candidates_kernel<<<1, 64, 0, st>>>(scratch + kRecE, scratch + kRecP);
+  chirality4_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(scratch + kRecP, (const double4*)corr, nullptr, n, (int32_t*)(scratch + kRecCnt));
+  SFM_TRY(check_launch());
+  SFM_TRY(hipMemcpyAsync(host_out, scratch, sizeof(double) * 70, hipMemcpyDeviceToHost, st));
+  return (int)hipStreamSynchronize(st);
+}
+
+int sfm_h_record_f64(const double* corr, int32_t n, const int32_t* row, double thr, uint8_t* mask_a, uint8_t* mask_b, double* scratch,
+                     double* host_out, void* stream) {
+  clear_stale_error();
+  if (!corr || !row || !mask_a || !mask_b || !scratch || !host_out || n <= 0) return SFM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  RowArg r;
+  for (int i = 0; i < 12; ++i) {
+    if (row[i] < 0 || row[i] >= n) return SFM_EINVAL;
+    r.v[i] = row[i];
+  }
+  SFM_TRY(hipMemsetAsync(scratch + kRecCnt, 0, 4 * sizeof(double), st));
+  SFM_TRY(hipMemsetAsync(scratch + kRecCnt2, 0, 4 * sizeof(double), st));
+  models_from_row_kernel<<<1, 64, 0, st>>>((const double4*)corr, r, scratch + kRecE, scratch + kRecH);
+  homography_to_rt_kernel<<<1, 1024, 0, st>>>(scratch + kRecH, (const double4*)corr, n, scratch + kRecRt);
+  for (int k = 0; k < 2; ++k) {
+    const double* E = scratch + kRecRt + (k ? 33 : 24);
+    uint8_t* mask = k ? mask_b : mask_a;
+    double* P = scratch + (k ? kRecP2 : kRecP);
+    mask_kernel<true><<<div_up(n, kBlock), kBlock, 0, st>>>(E, (const double4*)corr, n, 2.0 * thr * thr, mask,
+                                                          (int32_t*)(scratch + (k ? kRecMaskCnt2 : kRecMaskCnt)));
+    essential_candidates_kernel<<<1, 64, 0, st>>>(E, P);
+    chirality4_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(P, (const double4*)corr, mask, n, (int32_t*)(scratch + (k ? kRecCnt2 : kRecCnt)));
+  }
+  SFM_TRY(check_launch());
+  SFM_TRY(hipMemcpyAsync(host_out, scratch, sizeof(double) * 165, hipMemcpyDeviceToHost, st));
+  return (int)hipStreamSynchronize(st);
 }
 
 int sfm_triangulate_f64(const double* P1, const double* P2, const double* x1, const double* x2, int32_t m, int64_t ld, double* X,

@@ -468,6 +468,56 @@ def lm_translation(K, pts, cam_sizes, T0, iters, mu, want_history=False):
     return (T, hist) if want_history else T
 
 
+# ---- record events of the E/H replay ----------------------------------------------------------
+
+
+class RecordScratch:
+    """Device and host scratch of e_record / h_record (allocate once per image pair)."""
+
+    def __init__(self, n):
+        torch = C.torch_cuda()
+        k = int(C.load_library().sfm_record_scratch_doubles())
+        self.dev = _empty((k,), torch.float64)
+        self.host = np.zeros(k, np.float64)
+        self.n = n
+
+
+def _pick_candidate(host, p_off, c_off):
+    counts = host[c_off : c_off + 2].view(np.int32)[:4]
+    best, n = 0, -1
+    for i in range(4):  # first strict maximum (src/chirality_check.py:72-91)
+        if counts[i] > n:
+            best, n = i, int(counts[i])
+    P = host[p_off + 12 * best : p_off + 12 * best + 12].reshape(3, 4)
+    return P[:, :3].copy(), P[:, 3].copy(), n
+
+
+def e_record(corr, row, thr, scratch):
+    """src/ransac_algorithm.py:105-113 in one call: returns (R, T, mask uint8 device tensor)."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    n = corr.shape[0]
+    mask = _empty((n,), torch.uint8)
+    r = np.ascontiguousarray(row, np.int32)
+    C.check(lib.sfm_e_record_f64(C.dptr(corr), n, C.hptr(r), float(thr), C.dptr(mask), C.dptr(scratch.dev), C.hptr(scratch.host), C.stream_ptr()))
+    R, T, _ = _pick_candidate(scratch.host, 18, 66)
+    return R, T, mask
+
+
+def h_record(corr, row, thr, scratch):
+    """src/ransac_algorithm.py:121-147 in one call: ((R, T, count, mask), (R, T, count, mask)) for the two solutions."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    n = corr.shape[0]
+    ma, mb = _empty((n,), torch.uint8), _empty((n,), torch.uint8)
+    r = np.ascontiguousarray(row, np.int32)
+    C.check(lib.sfm_h_record_f64(C.dptr(corr), n, C.hptr(r), float(thr), C.dptr(ma), C.dptr(mb), C.dptr(scratch.dev), C.hptr(scratch.host),
+                                 C.stream_ptr()))
+    a = _pick_candidate(scratch.host, 18, 66) + (ma,)
+    b = _pick_candidate(scratch.host, 113, 161) + (mb,)
+    return a, b
+
+
 # ---- descriptor matching ---------------------------------------------------------------------
 
 

@@ -149,46 +149,20 @@ class GpuBackend:
         self.thr = float(err_threshold)
         self.corr = C.dev(ops.pack_corr(x1, x2))
         self.n = self.corr.shape[0]
+        self.scratch = ops.RecordScratch(self.n)
 
     def score(self, idx):
         d_idx = C.dev(idx, np.int32)
         ce, ch = ops.eh_score(self.corr, d_idx, self.thr, 3 * self.thr)
         return ce.cpu().numpy(), ch.cpu().numpy()
 
-    def _models(self, row):
-        return ops.eh_models(self.corr, C.dev(np.asarray(row)[None, :], np.int32))
-
-    def _decompose(self, E, mask):
-        P = ops.essential_candidates(E)
-        counts = ops.chirality4(P, self.corr, mask)
-        return P, counts
-
     def e_record(self, row):
-        """R, T of essential_to_RT over ALL points (src/ransac_algorithm.py:110) and the inlier mask."""
-        E, _ = self._models(row)
-        mask, _ = ops.epipolar_mask(E[0], self.corr, self.thr)
-        P, counts = self._decompose(E[0], None)
-        P = P.cpu().numpy()
-        bi, _ = first_strict_max(counts.cpu().numpy())
-        Pb = P[bi].reshape(3, 4)
-        return Pb[:, :3].copy(), Pb[:, 3].copy(), mask
+        """R, T of essential_to_RT over ALL points (src/ransac_algorithm.py:110) and the inlier mask: one library call."""
+        return ops.e_record(self.corr, row, self.thr, self.scratch)
 
     def h_record(self, row):
-        """Both homography solutions scored as src/ransac_algorithm.py:128-147."""
-        _, H = self._models(row)
-        rt = ops.homography_to_rt(H[0], self.corr)
-        out = []
-        staged = []
-        for off in (24, 33):
-            E = rt[off : off + 9]
-            mask, _ = ops.epipolar_mask(E, self.corr, self.thr)
-            P, counts = self._decompose(E, mask)
-            staged.append((P, counts, mask))
-        for P, counts, mask in staged:
-            bi, n = first_strict_max(counts.cpu().numpy())
-            Pb = P.cpu().numpy()[bi].reshape(3, 4)
-            out.append((Pb[:, :3].copy(), Pb[:, 3].copy(), n, mask))
-        return out[0], out[1]
+        """Both homography solutions scored as src/ransac_algorithm.py:128-147: one library call."""
+        return ops.h_record(self.corr, row, self.thr, self.scratch)
 
 
 def estimate_E_robust(K, x1, x2, pixel_threshold):
