@@ -379,6 +379,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
                                                                   long long nb, double two_thr_e2, double thr_h2, double xmax, double safety,
                                                                   int* __restrict__ up_e, int* __restrict__ up_h, int tiles_per_split,
                                                                   int use_atomics) {
+  __shared__ unsigned char fin[kBlock / 64][64];
   __shared__ uint4 bstage[kBlock / 64][64][6][2];
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long hyp = gid < nb ? gid : nb - 1;
@@ -393,6 +394,17 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
       gather_samples<double>(corr, idx + 12 * hyp, p8, p4);
       solve_E8<double>(p8, Ed);
       solve_H4<double>(p4, Hd);
+    }
+    // A model with a non-finite entry has the float64 count 0 (every comparison with NaN is false) but an undefined
+    // sign pattern here: its count is replaced by 0 when it is written.
+    {
+      double chk_e = 0.0, chk_h = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        chk_e = fma(Ed[i], 0.0, chk_e);  // NaN as soon as one entry is NaN or infinite
+        chk_h = fma(Hd[i], 0.0, chk_h);
+      }
+      fin[wave][lane] = (unsigned char)((chk_e == 0.0 ? 1 : 0) | (chk_h == 0.0 ? 2 : 0));  // parked in LDS: no register lives across the loop
     }
     double inv = to_unit_f32(Ed, unused, A);
     {
@@ -499,7 +511,9 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
     se[k] = ce[k] + __shfl_xor(ce[k], 32);
     sh[k] = ch[k] + __shfl_xor(ch[k], 32);
   }
-  const int oute = half ? se[1] : se[0], outh = half ? sh[1] : sh[0];  // lane L reports hypothesis L = 32*half + col
+  // lane L reports hypothesis L = 32*half + col, the one it solved itself
+  const unsigned ok = fin[wave][lane];
+  const int oute = (ok & 1u) ? (half ? se[1] : se[0]) : 0, outh = (ok & 2u) ? (half ? sh[1] : sh[0]) : 0;
   if (gid < nb) {
     if (use_atomics) {
       atomicAdd(up_e + gid, oute);
