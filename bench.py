@@ -464,7 +464,7 @@ def main():
                 "peak": PEAK_FP32_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/r01j_summary.txt):
+                # HBM bytes per launch from rocprofv3 PMC passes of this same command (the latest summary under profiles/):
                 # FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE; algorithmic bytes are
                 # 48 MB of index sets + 0.5 MB of matches read, 8 MB of counts written.
                 "traffic": PMC_TRAFFIC_BYTES if (n, B) == (10000, 1000000) else None,
