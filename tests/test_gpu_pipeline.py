@@ -194,3 +194,17 @@ def test_homography_to_RT_negates_its_argument_like_the_reference(sfm, golden):
         positives = np.sum(np.sum(x2 * (before @ x1), axis=0) > 0)
         expect = -before if positives < x1.shape[1] / 2 else before
         np.testing.assert_array_equal(Hm, expect)
+
+
+def test_c_abi_from_plain_cpp():
+    """tests/c_abi/c_abi_demo.cpp: the library driven from C++ with hipMalloc'd buffers (no Python, no torch in the
+    process); the program cross-checks the bulk arg-max step against exact scoring and the two translation RANSAC forms
+    against each other and exits non-zero on any difference."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c_abi", "c_abi_demo")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "c_abi_demo ok" in r.stdout
