@@ -338,7 +338,7 @@ def main():
         idx = _capi.dev(idx_host)
     else:
         idx = ops.index_sets(args.seed, base, B, n)
-        idx_host = idx.cpu().numpy()
+        idx_host = idx.cpu().numpy() if world == 1 else None  # only the single-GPU run re-checks a sample on the host
     corr32 = ops.corr_to_f32(corr)
     xmax = float(np.abs(np.concatenate([x1n[:2], x2n[:2]])).max())
     ce = torch.empty(B, dtype=torch.int32, device="cuda")
