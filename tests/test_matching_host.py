@@ -1,0 +1,67 @@
+"""Host side of the feature front-end without a GPU: features are detected once per (image, read mode), kept in
+memory and, when a cache directory is set, as .npz files; OpenCV is replaced by a stand-in module that counts calls."""
+import sys
+import types
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture
+def fake_cv2(monkeypatch):
+    calls = {"detect": 0, "imread": []}
+    cv2 = types.ModuleType("cv2")
+    cv2.IMREAD_GRAYSCALE = 0
+    cv2.COLOR_BGR2GRAY = 6
+
+    class KP:
+        def __init__(self, x, y):
+            self.pt = (x, y)
+
+    class Sift:
+        def detectAndCompute(self, gray, mask):
+            calls["detect"] += 1
+            rng = np.random.default_rng(int(gray.sum()) % 1000)
+            n = 17
+            return [KP(float(i), float(2 * i) + 0.5) for i in range(n)], rng.integers(0, 256, size=(n, 128)).astype(np.float32)
+
+    def imread(path, flag=1):
+        calls["imread"].append((path, flag))
+        return np.full((4, 4) if flag == 0 else (4, 4, 3), len(path) % 7, np.uint8)
+
+    cv2.imread = imread
+    cv2.cvtColor = lambda im, code: im[..., 0]
+    cv2.SIFT_create = lambda: Sift()
+    monkeypatch.setitem(sys.modules, "cv2", cv2)
+    return calls
+
+
+def test_features_are_detected_once_per_image_and_mode(fake_cv2, tmp_path, monkeypatch):
+    from sfm_hip import matching
+
+    monkeypatch.setattr(matching, "_features", {})
+    monkeypatch.setattr(matching, "FEATURE_CACHE_DIR", str(tmp_path / "cache"))
+    kp, d = matching.image_features("/data/img_001.jpg", "grayscale")
+    assert kp.shape == (17, 2) and kp.dtype == np.float32 and d.shape == (17, 128) and d.dtype == np.uint8
+    kp2, d2 = matching.image_features("/data/img_001.jpg", "grayscale")
+    assert kp2 is kp and fake_cv2["detect"] == 1  # second call: memory
+    matching.image_features("/data/img_001.jpg", "bgr2gray")  # the other read mode is a different image for OpenCV
+    assert fake_cv2["detect"] == 2 and fake_cv2["imread"][-1][1] == 1
+    # a new process (empty memory) finds the files
+    monkeypatch.setattr(matching, "_features", {})
+    kp3, d3 = matching.image_features("/data/img_001.jpg", "grayscale")
+    assert fake_cv2["detect"] == 2 and (kp3 == kp).all() and (d3 == d).all()
+    assert sorted(p.name for p in (tmp_path / "cache").iterdir()) == ["img_001.jpg.bgr2gray.sift.npz", "img_001.jpg.grayscale.sift.npz"]
+    with pytest.raises(ValueError):
+        matching.image_features("/data/img_002.jpg", "other")
+
+
+def test_matcher_refuses_to_run_without_gpu(fake_cv2):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sfm_hip import _capi, matching
+
+    with pytest.raises(_capi.SfmHipError):
+        matching.DescriptorSet(np.zeros((4, 128), np.uint8))
