@@ -63,6 +63,47 @@ def cpu_baseline(x1n, x2n, thr, n_matches, idx):
     }, idx, cE, cH
 
 
+def _cpu_worker(job):
+    """One worker of the all-cores CPU baseline: scores its slice of the sample with the NumPy oracle."""
+    n, seed, lo, hi = job
+    from oracle import sfm_oracle as orc
+    from sfm_hip import synthetic
+
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    sc = synthetic.two_view_scene(n=n, inlier_ratio=0.3, planar_ratio=0.5, seed=seed)
+    thr = 1.0 / sc["K"][0][0]
+    x1n = orc.normalize_K(sc["K"], sc["x1"])
+    x2n = orc.normalize_K(sc["K"], sc["x2"])
+    idx = np.random.default_rng(seed + lo).integers(0, n, size=(hi - lo, 12))
+    t0 = time.perf_counter()
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            orc.score_EH_batch(x1n, x2n, idx, thr)
+    else:
+        orc.score_EH_batch(x1n, x2n, idx, thr)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(n, seed, workers, hyps_per_worker):
+    """The same oracle on `workers` processes, each with its own range of hypotheses (the reference itself is single
+    threaded; this is what sharding its loop over the host cores would give)."""
+    import multiprocessing as mp
+
+    jobs = [(n, seed, w * hyps_per_worker, (w + 1) * hyps_per_worker) for w in range(workers)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(workers) as pool:
+        pool.map(_cpu_worker, [(n, seed, 0, 64)] * workers)  # start the workers, import NumPy
+        t1 = time.perf_counter()
+        busy = pool.map(_cpu_worker, jobs)
+        dt = time.perf_counter() - t1
+    return {"value": 2.0 * workers * hyps_per_worker * n / dt, "unit": "evals/s", "cores": workers, "kind": "port",
+            "sample": f"{workers} processes x {hyps_per_worker} hypotheses x {n} matches, NumPy float64 oracle, {dt:.1f} s wall "
+            f"(slowest worker {max(busy):.1f} s, pool start {t1 - t0:.1f} s not counted)"}
+
+
 def secondary_measurements(torch, ops, _capi, synthetic, seed):
     """Timings of the other rows of the path (not part of `value`): the batched 2-point
     translation RANSAC (12 cameras x 50 000 correspondences x 100 000 hypotheses) and the
@@ -286,11 +327,18 @@ def main():
                     help="torch.distributed backend for N>1: nccl (= RCCL over xGMI, one GPU per rank); gloo only to rehearse the "
                     "multi-rank path on a box with fewer GPUs than ranks (ranks then share GPUs)")
     ap.add_argument("--no-overlap", action="store_true", help="one step at a time on one stream (no overlap of a step's tail with the next step)")
+    ap.add_argument("--cpu-all-cores", type=int, default=0, metavar="WORKERS",
+                    help="also time the NumPy oracle on WORKERS host processes (hypothesis-range sharding) before the GPU is touched")
     ap.add_argument("--no-secondary", action="store_true", help="skip the T-RANSAC / LM / triangulation timings")
     ap.add_argument("--e2e", action="store_true", help="only run the synthetic dataset-5-shaped end-to-end geometry and print it")
     ap.add_argument("--e2e-cpu", action="store_true", help="with --e2e: also time the NumPy oracle end to end (minutes) and compare")
     ap.add_argument("--sweep", action="store_true", help="only run the match-count sweep (2k..200k matches) and print it")
     args = ap.parse_args()
+
+    all_cores = None
+    if args.cpu_all_cores > 0 and int(os.environ.get("RANK", "0")) == 0:
+        # worker processes are started before this process initialises the GPU
+        all_cores = cpu_baseline_all_cores(args.matches, args.seed, args.cpu_all_cores, 20000)
 
     import torch
     import torch.distributed as dist
@@ -498,6 +546,8 @@ def main():
         if args.cpu_sample > 0 and world == 1:
             base_res, idx_s, cE_s, cH_s = cpu_baseline(x1n, x2n, thr, n, idx_host[: args.cpu_sample])
             out["cpu_baseline"] = base_res
+            if all_cores is not None:
+                out["cpu_baseline_all_cores"] = all_cores
             # the CPU sample is the head of this rank's index stream: reuse it as a parity check
             ok = np.array([len(set(r[:8])) == 8 and len(set(r[8:])) == 4 for r in idx_s])
             gE = ce[: args.cpu_sample].cpu().numpy()
