@@ -472,6 +472,19 @@ def main():
         b.record()
     torch.cuda.synchronize()
     f64_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # the same exact counts from the matrix cores + float32 with float64 inside the error bands
+    ce2 = torch.empty_like(ce)
+    ch2 = torch.empty_like(ch)
+    mixed_ws = torch.empty(int(_capi.load_library().sfm_eh_score_mixed_workspace_bytes(B, n)), dtype=torch.uint8, device="cuda")
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+    for a, b in ev:
+        a.record()
+        ops.eh_score_mixed(corr, idx, thr, 3 * thr, xmax, out=(ce2, ch2), workspace=mixed_ws)
+        b.record()
+    torch.cuda.synchronize()
+    mixed_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    mixed_identical = bool(torch.equal(ce, ce2) and torch.equal(ch, ch2))
+    del mixed_ws, ce2, ch2
 
     if rank == 0:
         evals_per_step = 2.0 * B * n * world
@@ -541,6 +554,10 @@ def main():
                                      "frac": flops_per_launch / (tight_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS},
                 "f64_kernel": {"kernel": "eh_score_kernel", "kernel_ms": f64_ms, "achieved": flops_per_launch / (f64_ms * 1e-3) / 1e12,
                                "peak": PEAK_FP64_VALU_TFLOPS, "frac": flops_per_launch / (f64_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS},
+                "exact_mixed_kernel": {"kernel": "eh_score_mfma_kernel (the float64 counts of every hypothesis from matrix cores + float32, "
+                                       "float64 inside the error bands)", "kernel_ms": mixed_ms,
+                                       "achieved": flops_per_launch / (mixed_ms * 1e-3) / 1e12,
+                                       "counts_identical_to_f64_kernel": mixed_identical},
             },
         }
         if args.cpu_sample > 0 and world == 1:

@@ -92,6 +92,14 @@ int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_
                 double xmax, double safety, int32_t loose, void* workspace, int64_t workspace_bytes, int64_t* result,
                 void* stream);
 
+/* sfm_eh_score_f64 with the bulk of the residual tests on the bf16 matrix cores + float32 and IDENTICAL counts: the
+ * rows E x1, E^T x2 and H x1 come from MFMAs of three-piece splits; a pair whose float32 test value lies inside the
+ * rigorous error band around the threshold is re-evaluated with the float64 test inside the kernel.
+ * xmax: max |coordinate| over corr.  workspace: sfm_eh_score_mixed_workspace_bytes(nb, n) bytes, 256-byte aligned. */
+int64_t sfm_eh_score_mixed_workspace_bytes(int64_t nb, int32_t n);
+int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax,
+                       void* workspace, int64_t workspace_bytes, int32_t* count_e, int32_t* count_h, void* stream);
+
 /* The models themselves: F_out (estimate_F_DLT, :216-263, before the singular values are
  * replaced), E_out (after enforce_essential, :176-190) and H_out (estimate_H_DLT, :266-293),
  * each double[nb][9] or NULL.  Same solvers as sfm_eh_score_f64. */

@@ -525,6 +525,223 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// EXACT E/H counts (those of eh_score_kernel) at matrix-core + float32 cost: the scheme of
+// t_score_mfma_kernel applied to both tests.  Rows l = E x1, (m0, m1) = (E^T x2)_{0,1} and h = H x1 come
+// from bf16 MFMAs of three-piece splits; the float32 values
+//     dE = s^2 (n1 + n2) - k n1 n2        and        dH = dx^2 + dy^2 - (sqrt(T) hz)^2
+// decide a pair by their sign unless they lie inside a rigorous band around zero:
+//   epipolar: with f = |s| - sqrt(k) g(L1, L2) (g = L1 L2 / sqrt(L1^2 + L2^2), 1-Lipschitz in L1 and L2) the computed
+//   f_c is within G = Es + sqrt(k)(eL1 + eL2) of f and dE_c = (n1 + n2) f_c (|s_c| + sqrt(k) g_c); a pair with
+//   |f| <= G therefore has |dE_c| <= 4 G sqrt(k) sqrt(n1 n2 (n1 + n2)) + 4 G^2 (n1 + n2) (+ float32 rounding);
+//   transfer: as in t_score_mfma_kernel with r = |(dx, dy)| and q = sqrt(T) hz.
+// Pairs inside a band are re-evaluated with the float64 tests of eh_score_kernel (models parked in global scratch).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void corr_to_mfma2_kernel(const double4* __restrict__ corr, int n, int npad, uint4* __restrict__ pieces,
+                                                               float2* __restrict__ xy) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= npad) return;
+  uint4* out = pieces + 4 * (long long)j;
+  if (j < n) {
+    const double4 c = corr[j];
+    pack_pieces(c.x, c.y, 1.0, false, out[0], out[1]);
+    pack_pieces(c.z, c.w, 1.0, false, out[2], out[3]);
+    xy[j] = make_float2((float)c.z, (float)c.w);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = make_uint4(0, 0, 0, 0);
+    xy[j] = make_float2(0.0f, 0.0f);
+  }
+}
+
+__global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
+                                                                  const float2* __restrict__ xy, int n, const int32_t* __restrict__ idx,
+                                                                  long long nb, double two_thr_e2, double thr_h2, double xmax,
+                                                                  double* __restrict__ models, int* __restrict__ count_e,
+                                                                  int* __restrict__ count_h, int tiles_per_split, int use_atomics) {
+  __shared__ unsigned char fin[kBlock / 64][64];
+  __shared__ uint4 bstage[kBlock / 64][64][8][2];
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long hyp = gid < nb ? gid : nb - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const double safety = 2.0;
+  float ca_own, cb_own, c1_own, c0_own;
+  {
+    double Ed[9], Hd[9], A[9];
+    float unused[9];
+    {
+      double p8[8][4], p4[4][4];
+      gather_samples<double>(corr, idx + 12 * hyp, p8, p4);
+      solve_E8<double>(p8, Ed);
+      solve_H4<double>(p4, Hd);
+    }
+    {
+      double chk_e = 0.0, chk_h = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        chk_e = fma(Ed[i], 0.0, chk_e);
+        chk_h = fma(Hd[i], 0.0, chk_h);
+        models[18 * gid + i] = Ed[i];  // the float64 tests are scale dependent only through rounding: keep the solver's own scale
+        models[18 * gid + 9 + i] = Hd[i];
+      }
+      fin[wave][lane] = (unsigned char)((chk_e == 0.0 ? 1 : 0) | (chk_h == 0.0 ? 2 : 0));
+    }
+    double inv = to_unit_f32(Ed, unused, A);
+    {
+      const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
+      const double C0 = xmax * (A[0] + A[3]) + A[6], C1 = xmax * (A[1] + A[4]) + A[7];
+      const double Es = (kEpsMfma + 4.0 * kEps32) * (xmax * (R0 + R1) + R2);
+      const double eL = (kEpsMfma + 2.0 * kEps32) * (R0 + R1 + C0 + C1);
+      const double rk = sqrt(two_thr_e2);
+      const double G = safety * (Es + rk * eL);
+      ca_own = round_up_f32(4.0 * G * rk * (1.0 + 64.0 * kEps32));
+      cb_own = round_up_f32(4.0 * G * G * (1.0 + 64.0 * kEps32));
+    }
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+      pack_pieces(Ed[3 * v] * inv, Ed[3 * v + 1] * inv, Ed[3 * v + 2] * inv, true, bstage[wave][lane][v][0], bstage[wave][lane][v][1]);
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+      pack_pieces(Ed[v] * inv, Ed[3 + v] * inv, Ed[6 + v] * inv, true, bstage[wave][lane][3 + v][0], bstage[wave][lane][3 + v][1]);
+    inv = to_unit_f32(Hd, unused, A);
+    {
+      const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
+      const double rt = sqrt(thr_h2);
+      const double Dx = (kEpsMfma + 3.0 * kEps32) * (R0 + xmax * R2), Dy = (kEpsMfma + 3.0 * kEps32) * (R1 + xmax * R2);
+      const double eq = rt * (kEpsMfma + 2.0 * kEps32) * R2;
+      const double e = safety * (Dx + Dy + eq);
+      c1_own = round_up_f32(4.0 * e + 13.0 * kEps32 * rt * R2 * 1.001);
+      c0_own = round_up_f32(4.1 * e * e);
+    }
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+      pack_pieces(Hd[3 * v] * inv, Hd[3 * v + 1] * inv, Hd[3 * v + 2] * inv, true, bstage[wave][lane][5 + v][0], bstage[wave][lane][5 + v][1]);
+  }
+  __syncthreads();
+  bf16x8 B[2][8];
+  float ca[2], cb[2], c1[2], c0[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) B[k][v] = as_bf16x8(bstage[wave][32 * k + col][v][half]);
+    ca[k] = __shfl(ca_own, 32 * k + col);
+    cb[k] = __shfl(cb_own, 32 * k + col);
+    c1[k] = __shfl(c1_own, 32 * k + col);
+    c0[k] = __shfl(c0_own, 32 * k + col);
+  }
+  const float kf = (float)two_thr_e2, rtf = (float)sqrt(thr_h2);
+  const float cc = round_up_f32(28.0 * kEps32 * two_thr_e2);  // float32 rounding of dE near the threshold, doubled
+  const int apos = 16 * ((col >> 2) & 1) + (col & 3) + 4 * (col >> 3);  // see eh_upper_mfma_kernel
+  const int ntiles = (n + 31) / 32;
+  const int t0 = blockIdx.y * tiles_per_split;
+  const int t1 = min(ntiles, t0 + tiles_per_split);
+  const long long wave_hyp0 = (long long)blockIdx.x * blockDim.x + 64 * wave;
+  int ce[2] = {0, 0}, ch[2] = {0, 0};
+  const f32x16 zero = {0};
+  for (int t = t0; t < t1; ++t) {
+    const uint4* src = pieces + 4 * (long long)(t * 32 + apos) + half;
+    const bf16x8 A1 = as_bf16x8(src[0]), A2 = as_bf16x8(src[2]);
+    const int nv = min(16, max(0, n - (t * 32 + 16 * half)));
+    const unsigned vmask = (0xFFFFu << (16 - nv)) & 0xFFFFu;
+    float x2[16], y2[16];
+    {
+      const float4* q = reinterpret_cast<const float4*>(xy + t * 32 + 16 * half);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 v = q[i];
+        x2[2 * i] = v.x; y2[2 * i] = v.y; x2[2 * i + 1] = v.z; y2[2 * i + 1] = v.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      unsigned amb_e, amb_h;
+      {
+        const f32x16 l0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][0], zero, 0, 0, 0);
+        const f32x16 l1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][1], zero, 0, 0, 0);
+        const f32x16 l2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][2], zero, 0, 0, 0);
+        const f32x16 m0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B[k][3], zero, 0, 0, 0);
+        const f32x16 m1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B[k][4], zero, 0, 0, 0);
+        unsigned hneg = 0, hamb = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float s = fma(l0[i], x2[i], fma(l1[i], y2[i], l2[i]));
+          const float n1 = fma(l0[i], l0[i], l1[i] * l1[i]);
+          const float n2 = fma(m0[i], m0[i], m1[i] * m1[i]);
+          const float S = n1 + n2, P = n1 * n2;
+          const float d = fma(-kf, P, (s * s) * S);  // < 0 <=> inlier
+          hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d), 31);
+          // the constants are inflated so that "inside or on the band" reads "< band"; the floor keeps a degenerate
+          // epipolar line (n1 = n2 = 0 after float32 underflow) inside the band
+          const float band = fma(ca[k], __builtin_amdgcn_sqrtf(P * S), fma(cb[k], S, fma(cc, P, 1.0e-36f)));  // raw v_sqrt_f32: 1 ulp, inside the margin of ca
+          hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(d) - band), 31);  // < 0 <=> the float32 sign is not trusted
+        }
+        amb_e = hamb & vmask;
+        ce[k] += __popc(hneg & vmask & ~amb_e);
+      }
+      {
+        const f32x16 hx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][5], zero, 0, 0, 0);
+        const f32x16 hy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][6], zero, 0, 0, 0);
+        const f32x16 hz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][7], zero, 0, 0, 0);
+        unsigned hneg = 0, hamb = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float dx = fma(x2[i], hz[i], -hx[i]);
+          const float dy = fma(y2[i], hz[i], -hy[i]);
+          const float q = rtf * hz[i];
+          const float d = fma(-q, q, fma(dy, dy, dx * dx));
+          hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d), 31);
+          hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(d) - fma(c1[k], fabsf(q), c0[k])), 31);
+        }
+        amb_h = hamb & vmask;
+        ch[k] += __popc(hneg & vmask & ~amb_h);
+      }
+      if (amb_e | amb_h) {
+        const double* M = models + 18 * (wave_hyp0 + 32 * k + col);
+        if (amb_e) {
+          double E[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) E[i] = M[i];
+          while (amb_e) {
+            const int b = __ffs((int)amb_e) - 1;  // bit 15-i of a history is match 16*half + i of the tile
+            amb_e &= amb_e - 1;
+            const double4 p = corr[t * 32 + 16 * half + 15 - b];
+            ce[k] += epipolar_inlier<double>(E, p.x, p.y, p.z, p.w, two_thr_e2) ? 1 : 0;
+          }
+        }
+        if (amb_h) {
+          double H[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) H[i] = M[9 + i];
+          while (amb_h) {
+            const int b = __ffs((int)amb_h) - 1;
+            amb_h &= amb_h - 1;
+            const double4 p = corr[t * 32 + 16 * half + 15 - b];
+            ch[k] += transfer_inlier<double>(H, p.x, p.y, p.z, p.w, thr_h2) ? 1 : 0;
+          }
+        }
+      }
+    }
+  }
+  int se[2], sh[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    se[k] = ce[k] + __shfl_xor(ce[k], 32);
+    sh[k] = ch[k] + __shfl_xor(ch[k], 32);
+  }
+  const unsigned ok = fin[wave][lane];
+  const int oute = (ok & 1u) ? (half ? se[1] : se[0]) : 0, outh = (ok & 2u) ? (half ? sh[1] : sh[0]) : 0;
+  if (gid < nb) {
+    if (use_atomics) {
+      atomicAdd(count_e + gid, oute);
+      atomicAdd(count_h + gid, outh);
+    } else {
+      count_e[gid] = oute;
+      count_h[gid] = outh;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void corr_to_f32_kernel(const double4* __restrict__ corr, int n, float4* __restrict__ corr32) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) {
@@ -1366,6 +1583,12 @@ inline int choose_splits(long long tiles, int npoints) {
 
 }  // namespace
 
+#define SFM_TRY(expr)            \
+  do {                           \
+    int rc_ = (int)(expr);       \
+    if (rc_ != 0) return rc_;    \
+  } while (0)
+
 extern "C" {
 
 const char* sfm_hip_error_string(int code) {
@@ -1494,6 +1717,41 @@ int sfm_eh_upper_mfma_f32(const double* corr, const void* corrm, int32_t n, cons
   return launch_eh_upper_mfma(corr, corrm, n, idx, nb, thr_e, thr_h, xmax, safety, up_e, up_h, (hipStream_t)stream);
 }
 
+int64_t sfm_eh_score_mixed_workspace_bytes(int64_t nb, int32_t n) {
+  if (nb < 0 || n <= 0) return -1;
+  const int64_t tiles = (nb + kBlock - 1) / kBlock;
+  return ((int64_t)padded32(n) * 72 + 255) / 256 * 256 + tiles * kBlock * 18 * (int64_t)sizeof(double);
+}
+
+int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax, void* workspace,
+                       int64_t workspace_bytes, int32_t* count_e, int32_t* count_h, void* stream) {
+  clear_stale_error();
+  if (!corr || !idx || !count_e || !count_h || !workspace || n <= 0 || nb < 0) return SFM_EINVAL;
+  if (!(xmax > 0.0 && xmax < 1.0e6) || ((uintptr_t)workspace & 255u) != 0) return SFM_EINVAL;
+  if (workspace_bytes < sfm_eh_score_mixed_workspace_bytes(nb, n)) return SFM_EINVAL;
+  if (nb == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const long long tiles = (nb + kBlock - 1) / kBlock;
+  if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
+  const int npad = padded32(n);
+  const int ntiles = npad / 32;
+  uint4* pieces = (uint4*)workspace;
+  float2* xy = (float2*)((char*)workspace + (size_t)npad * 64);
+  double* models = (double*)((char*)workspace + ((size_t)npad * 72 + 255) / 256 * 256);
+  int splits = choose_splits(tiles, n);
+  if (splits > ntiles) splits = ntiles;
+  const int tps = div_up(ntiles, splits);
+  if (splits > 1) {
+    SFM_TRY(hipMemsetAsync(count_e, 0, sizeof(int32_t) * nb, st));
+    SFM_TRY(hipMemsetAsync(count_h, 0, sizeof(int32_t) * nb, st));
+  }
+  corr_to_mfma2_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, pieces, xy);
+  SFM_TRY(check_launch());
+  eh_score_mfma_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e,
+                                                                        thr_h * thr_h, xmax, models, count_e, count_h, tps, splits > 1);
+  return check_launch();
+}
+
 // ---- the whole bound cascade as one call -------------------------------------------------
 namespace {
 constexpr int kCandCap = 65536;      // candidates kept per class; more than that -> score everything in float64
@@ -1541,11 +1799,6 @@ int64_t sfm_eh_best_workspace_bytes(int64_t nb, int32_t n) {
   return (nb < 0 || n < 0) ? -1 : (int64_t)carve(nullptr, nb, n, &w);
 }
 
-#define SFM_TRY(expr)            \
-  do {                           \
-    int rc_ = (int)(expr);       \
-    if (rc_ != 0) return rc_;    \
-  } while (0)
 
 int64_t sfm_eh_best_pending_bytes(void) { return (int64_t)sizeof(BestPending); }
 

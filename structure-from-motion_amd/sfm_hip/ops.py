@@ -52,6 +52,24 @@ def eh_score(corr, idx, thr_e, thr_h, out=None):
     return ce, ch
 
 
+def eh_score_mixed(corr, idx, thr_e, thr_h, xmax, out=None, workspace=None):
+    """The counts of eh_score (identical for every hypothesis) with the residual tests on the matrix cores + float32 and a
+    float64 re-evaluation of the pairs inside the error band.  xmax: max |coordinate| over corr (host float)."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    nb, n = idx.shape[0], corr.shape[0]
+    if out is None:
+        ce = _empty((nb,), torch.int32)
+        ch = _empty((nb,), torch.int32)
+    else:
+        ce, ch = out
+    if workspace is None:
+        workspace = _empty((max(256, int(lib.sfm_eh_score_mixed_workspace_bytes(nb, n))),), torch.uint8)
+    C.check(lib.sfm_eh_score_mixed(C.dptr(corr), n, C.dptr(idx), nb, float(thr_e), float(thr_h), float(xmax), C.dptr(workspace),
+                                   workspace.numel(), C.dptr(ce), C.dptr(ch), C.stream_ptr()))
+    return ce, ch
+
+
 def corr_to_f32(corr):
     torch = C.torch_cuda()
     lib = C.load_library()

@@ -441,3 +441,54 @@ def test_mixed_translation_ransac_counts_are_identical_to_float64(ops, dev):
     assert np.array_equal(T64.cpu().numpy(), Tmx.cpu().numpy(), equal_nan=True)
     assert int(c64[5, 0]) >= 2  # the adversarial camera really has points on both sides of the circle
     assert 100 < int(c64[5, 0]) < 3900
+
+
+@pytest.mark.parametrize("n,B,inl,pl,px,seed", [(1500, 20000, 0.5, 0.5, 1.0, 1), (10000, 60000, 0.3, 0.5, 1.0, 0), (97, 4099, 0.8, 1.0, 0.5, 2),
+                                                (12, 64, 0.9, 0.0, 3.0, 3), (5000, 3000, 0.0, 0.5, 1.0, 4), (2048, 257, 0.95, 0.5, 1.0, 5)])
+def test_mixed_eh_scoring_counts_are_identical_to_float64(ops, dev, n, B, inl, pl, px, seed):
+    """sfm_eh_score_mixed (matrix cores + float32, float64 inside the error bands) against sfm_eh_score_f64: every count."""
+    import torch
+
+    sc, x1, x2 = scene(n=n, inl=inl, pl=pl, seed=seed)
+    corr_h = ops.pack_corr(x1, x2)
+    corr = dev(corr_h)
+    idx = ops.index_sets(seed, 0, B, n)
+    thr = px / sc["K"][0][0]
+    ce, ch = ops.eh_score(corr, idx, thr, 3 * thr)
+    me, mh = ops.eh_score_mixed(corr, idx, thr, 3 * thr, float(np.abs(corr_h).max()))
+    assert torch.equal(ce, me) and torch.equal(ch, mh)
+
+
+def test_mixed_eh_scoring_on_the_threshold_and_degenerate_inputs(ops, dev):
+    """Matches constructed to lie within 1e-7 (relative) of the transfer threshold of a known homography and of the
+    epipolar threshold of a known essential matrix, duplicated sample indices, and a set of identical matches."""
+    import torch
+
+    rng = np.random.default_rng(12)
+    n = 4000
+    thr = 1.0 / 2400.0
+    x1 = rng.uniform(-0.4, 0.4, size=(2, n))
+    # planar scene under a rotation + translation -> exact homography; second view displaced by ~3*thr from H x1
+    Hm = np.array([[0.995, -0.01, 0.02], [0.012, 1.003, -0.015], [0.03, -0.02, 1.0]])
+    p = Hm @ np.vstack([x1, np.ones(n)])
+    x2 = p[:2] / p[2]
+    ang = rng.uniform(0, 2 * np.pi, n)
+    rad = 3 * thr * (1.0 + rng.integers(-40, 41, n) * 1e-7)
+    x2 = x2 + rad * np.vstack([np.cos(ang), np.sin(ang)])
+    x2[:, :40] = (p[:2] / p[2])[:, :40]  # exact matches, so that samples drawn from them reproduce H (and a valid E)
+    corr_h = np.ascontiguousarray(np.vstack([x1, x2]).T)
+    corr = dev(corr_h)
+    B = 3000
+    idx_h = rng.integers(0, n, size=(B, 12)).astype(np.int32)
+    idx_h[:500] = rng.integers(0, 40, size=(500, 12))  # samples among the exact matches
+    idx_h[500:520, 1] = idx_h[500:520, 0]  # duplicated indices
+    idx = dev(idx_h)
+    ce, ch = ops.eh_score(corr, idx, thr, 3 * thr)
+    me, mh = ops.eh_score_mixed(corr, idx, thr, 3 * thr, float(np.abs(corr_h).max()))
+    assert torch.equal(ce, me) and torch.equal(ch, mh)
+    assert 500 < int(ch[:500].max()) < n - 500  # the constructed matches really straddle the threshold
+    same = dev(np.tile(np.array([[0.1, -0.2, 0.12, -0.18]]), (200, 1)))
+    idx2 = ops.index_sets(3, 0, 1000, 200)
+    a = ops.eh_score(same, idx2, 4e-4, 1.2e-3)
+    b = ops.eh_score_mixed(same, idx2, 4e-4, 1.2e-3, 0.2)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
