@@ -32,7 +32,7 @@ FLOPS_PER_E_EVAL = 36  # algorithmic cost of one symmetric-epipolar residual tes
 FLOPS_PER_H_EVAL = 21  # one transfer-error residual test
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32
 PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector FP64 (half of the FP32 vector rate)
-PMC_TRAFFIC_BYTES = (2 * 26443.4 + 7812.5) * 1024  # FETCH_SIZE x2 + WRITE_SIZE of the dominant kernel, KB -> bytes
+PMC_TRAFFIC_BYTES = (2 * 26443.3 + 7812.5) * 1024  # FETCH_SIZE x2 + WRITE_SIZE of the dominant kernel, KB -> bytes
 
 
 def cpu_baseline(x1n, x2n, thr, n_matches, idx):
