@@ -77,3 +77,18 @@ def test_replay_never_draws_past_a_finite_limit():
     assert st.it == ref["iterations"]
     np.testing.assert_array_equal(np.random.randint(0, 1000, 3), after_ref)
     assert sum(be.blocks) >= st.it
+
+
+def test_record_event_candidate_choice_is_the_first_strict_maximum():
+    """The host half of a record event: among the four [R|t] candidates the first strict maximum of the chirality counts
+    wins and an all-zero vote keeps candidate 0 (src/chirality_check.py:72-91: best count starts at -1)."""
+    from sfm_hip import ops
+
+    host = np.zeros(256)
+    P = np.arange(48, dtype=np.float64).reshape(4, 3, 4)
+    host[18:66] = P.ravel()
+    for counts, want in [([5, 9, 9, 2], 1), ([0, 0, 0, 0], 0), ([3, 3, 3, 3], 0), ([1, 2, 3, 4], 3)]:
+        host[66:68] = np.array(counts, np.int32).view(np.float64)
+        R, T, n = ops._pick_candidate(host, 18, 66)
+        assert n == counts[want]
+        assert (R == P[want][:, :3]).all() and (T == P[want][:, 3]).all()
