@@ -535,7 +535,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
 //   f_c is within G = Es + sqrt(k)(eL1 + eL2) of f and dE_c = (n1 + n2) f_c (|s_c| + sqrt(k) g_c); a pair with
 //   |f| <= G therefore has |dE_c| <= 4 G sqrt(k) sqrt(n1 n2 (n1 + n2)) + 4 G^2 (n1 + n2) (+ float32 rounding);
 //   transfer: as in t_score_mfma_kernel with r = |(dx, dy)| and q = sqrt(T) hz.
-// Pairs inside a band are re-evaluated with the float64 tests of eh_score_kernel (models parked in global scratch).
+// Pairs inside a band are re-evaluated with the float64 tests of eh_score_kernel (models parked in LDS).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void corr_to_mfma2_kernel(const double4* __restrict__ corr, int n, int npad, uint4* __restrict__ pieces,
                                                                float2* __restrict__ xy) {
@@ -557,8 +557,8 @@ __global__ __launch_bounds__(kBlock) void corr_to_mfma2_kernel(const double4* __
 __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
                                                                   const float2* __restrict__ xy, int n, const int32_t* __restrict__ idx,
                                                                   long long nb, double two_thr_e2, double thr_h2, double xmax,
-                                                                  double* __restrict__ models, int* __restrict__ count_e,
-                                                                  int* __restrict__ count_h, int tiles_per_split, int use_atomics) {
+                                                                  int* __restrict__ count_e, int* __restrict__ count_h,
+                                                                  int tiles_per_split, int use_atomics) {
   __shared__ unsigned char fin[kBlock / 64][64];
   __shared__ uint4 bstage[kBlock / 64][64][8][2];
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -567,8 +567,9 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
   const int col = lane & 31, half = lane >> 5;
   const double safety = 2.0;
   float ca_own, cb_own, c1_own, c0_own;
+  double Ed[9], Hd[9];
   {
-    double Ed[9], Hd[9], A[9];
+    double A[9];
     float unused[9];
     {
       double p8[8][4], p4[4][4];
@@ -582,8 +583,6 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
       for (int i = 0; i < 9; ++i) {
         chk_e = fma(Ed[i], 0.0, chk_e);
         chk_h = fma(Hd[i], 0.0, chk_h);
-        models[18 * gid + i] = Ed[i];  // the float64 tests are scale dependent only through rounding: keep the solver's own scale
-        models[18 * gid + 9 + i] = Hd[i];
       }
       fin[wave][lane] = (unsigned char)((chk_e == 0.0 ? 1 : 0) | (chk_h == 0.0 ? 2 : 0));
     }
@@ -630,13 +629,22 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
     c1[k] = __shfl(c1_own, 32 * k + col);
     c0[k] = __shfl(c0_own, 32 * k + col);
   }
+  // the piece vectors now live in registers: the wave's part of the staging area is reused for the float64 models (in the
+  // solver's own scale) that the re-evaluation of a pair inside a band needs
+  __syncthreads();
+  double* mstage = reinterpret_cast<double*>(&bstage[wave][0][0][0]);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    mstage[18 * lane + i] = Ed[i];
+    mstage[18 * lane + 9 + i] = Hd[i];
+  }
+  __syncthreads();
   const float kf = (float)two_thr_e2, rtf = (float)sqrt(thr_h2);
   const float cc = round_up_f32(28.0 * kEps32 * two_thr_e2);  // float32 rounding of dE near the threshold, doubled
   const int apos = 16 * ((col >> 2) & 1) + (col & 3) + 4 * (col >> 3);  // see eh_upper_mfma_kernel
   const int ntiles = (n + 31) / 32;
   const int t0 = blockIdx.y * tiles_per_split;
   const int t1 = min(ntiles, t0 + tiles_per_split);
-  const long long wave_hyp0 = (long long)blockIdx.x * blockDim.x + 64 * wave;
   int ce[2] = {0, 0}, ch[2] = {0, 0};
   const f32x16 zero = {0};
   for (int t = t0; t < t1; ++t) {
@@ -697,7 +705,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
         ch[k] += __popc(hneg & vmask & ~amb_h);
       }
       if (amb_e | amb_h) {
-        const double* M = models + 18 * (wave_hyp0 + 32 * k + col);
+        const double* M = mstage + 18 * (32 * k + col);
         if (amb_e) {
           double E[9];
 #pragma unroll
@@ -1719,8 +1727,7 @@ int sfm_eh_upper_mfma_f32(const double* corr, const void* corrm, int32_t n, cons
 
 int64_t sfm_eh_score_mixed_workspace_bytes(int64_t nb, int32_t n) {
   if (nb < 0 || n <= 0) return -1;
-  const int64_t tiles = (nb + kBlock - 1) / kBlock;
-  return ((int64_t)padded32(n) * 72 + 255) / 256 * 256 + tiles * kBlock * 18 * (int64_t)sizeof(double);
+  return ((int64_t)padded32(n) * 72 + 255) / 256 * 256;
 }
 
 int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax, void* workspace,
@@ -1737,7 +1744,6 @@ int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_
   const int ntiles = npad / 32;
   uint4* pieces = (uint4*)workspace;
   float2* xy = (float2*)((char*)workspace + (size_t)npad * 64);
-  double* models = (double*)((char*)workspace + ((size_t)npad * 72 + 255) / 256 * 256);
   int splits = choose_splits(tiles, n);
   if (splits > ntiles) splits = ntiles;
   const int tps = div_up(ntiles, splits);
@@ -1748,7 +1754,7 @@ int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_
   corr_to_mfma2_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, pieces, xy);
   SFM_TRY(check_launch());
   eh_score_mfma_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e,
-                                                                        thr_h * thr_h, xmax, models, count_e, count_h, tps, splits > 1);
+                                                                        thr_h * thr_h, xmax, count_e, count_h, tps, splits > 1);
   return check_launch();
 }
 
