@@ -32,7 +32,7 @@ FLOPS_PER_E_EVAL = 36  # algorithmic cost of one symmetric-epipolar residual tes
 FLOPS_PER_H_EVAL = 21  # one transfer-error residual test
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32
 PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector FP64 (half of the FP32 vector rate)
-PMC_TRAFFIC_BYTES = (2 * 26443.3 + 7812.5) * 1024  # FETCH_SIZE x2 + WRITE_SIZE of the dominant kernel, KB -> bytes
+PMC_TRAFFIC_BYTES = (2 * 26441.5 + 7812.5) * 1024  # FETCH_SIZE x2 + WRITE_SIZE of the dominant kernel, KB -> bytes
 
 
 def cpu_baseline(x1n, x2n, thr, n_matches, idx):
@@ -438,7 +438,7 @@ def main():
     dt = float(tmax.item())
 
     # ---- kernel time of the dominant kernel, HIP events on the launch stream -----------------
-    corrm = ops.corr_to_mfma(corr)
+    corrm = ops.corr_to_mfma(corr, thr)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in ev:
         a.record()
@@ -536,15 +536,15 @@ def main():
                 "algorithmic cost of the reference's tests (36 flops per E residual + 21 per H residual) and is priced against "
                 "the float32 vector peak, which bounds the part that is not GEMM shaped; the kernel reaches the exact winner with "
                 "cheaper implied tests, moves the two 3x3 products (24 of its 43 flops per pair) to the matrix cores and "
-                "executes 13 vector instructions per pair (see executed_valu_tflops). profiles/microbench/valu_rates measures "
+                "executes 12 vector instructions per pair (see executed_valu_tflops). profiles/microbench/valu_rates measures "
                 "131.8 TFLOP/s for a pure v_fma_f32 stream on this chip",
-                "executed_valu_tflops": 19.0 * B * n / (kern_ms * 1e-3) / 1e12,
+                "executed_valu_tflops": 18.0 * B * n / (kern_ms * 1e-3) / 1e12,
                 # frac can exceed 1 against the vector peak alone because 24 of the 57 algorithmic flops per pair run on the
                 # matrix cores.  Ceiling with the matrix cores counted: the GEMM-shaped part of the reference's tests
                 # (E x1, E^T x2, H x1 = 32 flops per pair) hidden entirely behind the vector work, the other 25 flops at the
                 # float32 vector peak.
                 "combined_ceiling": {"peak": PEAK_FP32_VALU_TFLOPS * 57.0 / 25.0, "frac": achieved / (PEAK_FP32_VALU_TFLOPS * 57.0 / 25.0),
-                                     "valu_issue_frac_at_2p4GHz": 13.0 * B * n / 64 / 1024 / (kern_ms * 1e-3) / 1.2e9,
+                                     "valu_issue_frac_at_2p4GHz": 12.0 * B * n / 64 / 1024 / (kern_ms * 1e-3) / 1.2e9,
                                      "mfma_busy_frac_at_2p4GHz": 6.0 * B * n / 1024 / 1024 * 32 / 2.4e9 / (kern_ms * 1e-3)},
                 "loose_valu_kernel": {"kernel": "eh_upper_kernel<true>", "kernel_ms": loose_valu_ms,
                                       "achieved": flops_per_launch / (loose_valu_ms * 1e-3) / 1e12,

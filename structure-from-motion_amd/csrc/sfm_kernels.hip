@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void eh_upper_kernel(const double4* __restr
 // coordinate one row of the product is a K = 6 + 6 + 3 = 15 contraction = ONE
 // v_mfma_f32_32x32x16_bf16 per 32 matches x 32 hypotheses, a quarter of the VALU time of the
 // two fmas it replaces.  The VALU keeps only what is not GEMM shaped (s = l.x2, |l|^2, the
-// box test): 13 instead of 26 instructions per pair, all on VGPR operands.
+// box test): 12 instead of 26 instructions per pair, all on VGPR operands.
 //
 // A wave solves 64 hypotheses (one per lane, float64, as everywhere else), publishes their
 // piece vectors through LDS and then owns two column blocks of 32 hypotheses; in the 32x32
@@ -352,10 +352,19 @@ __device__ __forceinline__ void pack_pieces(double a, double b, double c, bool m
   hi = make_uint4(e[8] | (e[9] << 16), e[10] | (e[11] << 16), e[12] | (e[13] << 16), e[14] | (e[15] << 16));
 }
 
+// Uniform constants of the matrix-core pre-filter.  Both tests are homogeneous in the model, so every model is scaled
+// such that ITS error bound G equals the fixed kGe / kGh; with a fixed mu the slack constants are then the same for all
+// hypotheses.  Dividing the one-sided epipolar test s^2 - c < k1 n1 by k1 = k (1 + mu) moves k1 into the match side:
+//     (l0 x2' + l1 y2' + l2')^2 - c' < l0^2 + l1^2,   x2' = x2 / sqrt(k1), y2' = y2 / sqrt(k1), l2' = l2 / sqrt(k1), c' = c / k1
+// (three fmas after s instead of four instructions); the box test is divided by sqrt(k1) as well, so that one scaled
+// copy of (x2, y2) serves both:  |x2' hz - hx'| < rt' |hz| + g'  with hx' = hx / sqrt(k1), rt' = rt / sqrt(k1), g' = g / sqrt(k1).
+constexpr double kGe = 0x1.0p-18, kGh = 0x1.0p-18, kMuE = 0.025;
+__host__ __device__ inline double uniform_k1(double two_thr_e2) { return two_thr_e2 * (1.0 + kMuE) * (1.0 + 32.0 * kEps32); }
+
 // Match-side operands for the matrix-core pre-filter: pieces[npad][2] (the 16 bf16 of (x1, y1, 1)) and
-// xy[npad] = float32 (x2, y2); npad = n rounded up to 32 (the scoring kernel masks the padding).
-__global__ __launch_bounds__(kBlock) void corr_to_mfma_kernel(const double4* __restrict__ corr, int n, int npad, uint4* __restrict__ pieces,
-                                                              float2* __restrict__ xy) {
+// xy[npad] = float32 (x2, y2) / sqrt(k1); npad = n rounded up to 32 (the scoring kernel masks the padding).
+__global__ __launch_bounds__(kBlock) void corr_to_mfma_kernel(const double4* __restrict__ corr, int n, int npad, double inv_sqrt_k1,
+                                                              uint4* __restrict__ pieces, float2* __restrict__ xy) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= npad) return;
   if (j < n) {
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void corr_to_mfma_kernel(const double4* __r
     pack_pieces(c.x, c.y, 1.0, false, lo, hi);
     pieces[2 * j] = lo;
     pieces[2 * j + 1] = hi;
-    xy[j] = make_float2((float)c.z, (float)c.w);
+    xy[j] = make_float2((float)(c.z * inv_sqrt_k1), (float)(c.w * inv_sqrt_k1));
   } else {
     pieces[2 * j] = make_uint4(0, 0, 0, 0);
     pieces[2 * j + 1] = make_uint4(0, 0, 0, 0);
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
   const long long hyp = gid < nb ? gid : nb - 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
-  float k1_own, c_own, rt_own, g_own;
+  const double inv_sqrt_k1 = 1.0 / sqrt(uniform_k1(two_thr_e2));
   {
     double Ed[9], Hd[9], A[9];
     float unused[9];
@@ -413,42 +422,38 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
       const double Es = (kEpsMfma + 4.0 * kEps32) * (xmax * (R0 + R1) + R2);
       // |L - L_true|, L = |(l0, l1)|: errors of l0 and l1 plus the float32 evaluation of l0^2 + l1^2
       const double eL = (kEpsMfma + 2.0 * kEps32) * (R0 + R1);
-      const double rk = sqrt(two_thr_e2);
-      const double G = safety * (Es + rk * eL);
-      double mu = 2.0 * G / rk;  // balances the two slack terms for epipolar lines of norm ~0.5
-      mu = mu < 1.0e-3 ? 1.0e-3 : (mu > 0.25 ? 0.25 : mu);
-      k1_own = round_up_f32(two_thr_e2 * (1.0 + mu) * (1.0 + 16.0 * kEps32));
-      c_own = round_up_f32(G * G * (1.0 + 1.0 / mu) * (1.0 + 16.0 * kEps32));
+      const double G = safety * (Es + sqrt(two_thr_e2) * eL);
+      inv *= kGe / G;  // now this model's G is kGe (G > 0: the unit-scaled model has an entry of magnitude 1)
     }
 #pragma unroll
-    for (int v = 0; v < 3; ++v)
-      pack_pieces(Ed[3 * v] * inv, Ed[3 * v + 1] * inv, Ed[3 * v + 2] * inv, true, bstage[wave][lane][v][0], bstage[wave][lane][v][1]);
+    for (int v = 0; v < 3; ++v) {
+      const double sc = v == 2 ? inv * inv_sqrt_k1 : inv;
+      pack_pieces(Ed[3 * v] * sc, Ed[3 * v + 1] * sc, Ed[3 * v + 2] * sc, true, bstage[wave][lane][v][0], bstage[wave][lane][v][1]);
+    }
     inv = to_unit_f32(Hd, unused, A);
     {
       const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
       const double ez = kEpsMfma * R2;
       const double Dx = (kEpsMfma + 3.0 * kEps32) * (R0 + xmax * R2), Dy = (kEpsMfma + 3.0 * kEps32) * (R1 + xmax * R2);
-      const double rt = sqrt(thr_h2);
-      const double G = safety * (rt * ez + Dx + Dy);
-      rt_own = round_up_f32(rt * (1.0 + 16.0 * kEps32));
-      g_own = round_up_f32(G * (1.0 + 16.0 * kEps32));
+      const double G = safety * (sqrt(thr_h2) * ez + Dx + Dy);
+      inv *= kGh / G;
     }
 #pragma unroll
-    for (int v = 0; v < 3; ++v)
-      pack_pieces(Hd[3 * v] * inv, Hd[3 * v + 1] * inv, Hd[3 * v + 2] * inv, true, bstage[wave][lane][3 + v][0], bstage[wave][lane][3 + v][1]);
+    for (int v = 0; v < 3; ++v) {
+      const double sc = v == 2 ? inv : inv * inv_sqrt_k1;
+      pack_pieces(Hd[3 * v] * sc, Hd[3 * v + 1] * sc, Hd[3 * v + 2] * sc, true, bstage[wave][lane][3 + v][0], bstage[wave][lane][3 + v][1]);
+    }
   }
   __syncthreads();
   bf16x8 B[2][6];
-  float k1[2], cc[2], rt[2], gg[2];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 2; ++k)
 #pragma unroll
     for (int v = 0; v < 6; ++v) B[k][v] = as_bf16x8(bstage[wave][32 * k + col][v][half]);
-    k1[k] = __shfl(k1_own, 32 * k + col);
-    cc[k] = __shfl(c_own, 32 * k + col);
-    rt[k] = __shfl(rt_own, 32 * k + col);
-    gg[k] = __shfl(g_own, 32 * k + col);
-  }
+  // c' = G^2 (1 + 1/mu) / k1, rt' = sqrt(T) / sqrt(k1), g' = G / sqrt(k1), each rounded up with room for the float32 roundings
+  const float cprime = round_up_f32(kGe * kGe * (1.0 + 1.0 / kMuE) * inv_sqrt_k1 * inv_sqrt_k1 * (1.0 + 32.0 * kEps32));
+  const float rtp = round_up_f32(sqrt(thr_h2) * inv_sqrt_k1 * (1.0 + 16.0 * kEps32));
+  const float gp = round_up_f32(kGh * inv_sqrt_k1 * (1.0 + 16.0 * kEps32));
   // accumulator register i of a lane in half h is matrix row (i&3) + 8(i>>2) + 4h; the A row that
   // lane `col` supplies is loaded from the match whose position in the tile is 16h' + i for that row,
   // so that half h scores the 16 consecutive matches 16h .. 16h+15 of the tile
@@ -481,9 +486,8 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
         const f32x16 l2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][2], zero, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float s = fma(l0[i], x2[i], fma(l1[i], y2[i], l2[i]));
-          const float n1 = fma(l0[i], l0[i], l1[i] * l1[i]);
-          const float d = fma(-k1[k], n1, fma(s, s, -cc[k]));  // inlier (or within the slack) <=> d < 0
+          const float s = fma(l0[i], x2[i], fma(l1[i], y2[i], l2[i]));  // s / sqrt(k1)
+          const float d = fma(s, s, fma(-l1[i], l1[i], fma(-l0[i], l0[i], -cprime)));  // inlier (or within the slack) <=> d < 0
           he[k] = __builtin_amdgcn_alignbit(he[k], __float_as_uint(d), 31);  // shift the sign bit into the history
         }
         ce[k] += __popc(he[k] & vmask);
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
         for (int i = 0; i < 16; ++i) {
           const float dx = fma(x2[i], hz[i], -hx[i]);
           const float dy = fma(y2[i], hz[i], -hy[i]);
-          const float lim = fma(rt[k], fabsf(hz[i]), gg[k]);
+          const float lim = fma(rtp, fabsf(hz[i]), gp);
           const float d = fmaxf(fabsf(dx), fabsf(dy)) - lim;
           hh[k] = __builtin_amdgcn_alignbit(hh[k], __float_as_uint(d), 31);
         }
@@ -1682,17 +1686,17 @@ static inline int padded32(int n) { return (n + 31) & ~31; }
 
 int64_t sfm_corr_mfma_bytes(int32_t n) { return n <= 0 ? 0 : (int64_t)padded32(n) * 40; }
 
-static int launch_corr_to_mfma(const double* corr, int32_t n, void* corrm, hipStream_t st) {
-  if (!corr || !corrm || n <= 0 || ((uintptr_t)corrm & 15u) != 0) return SFM_EINVAL;
+static int launch_corr_to_mfma(const double* corr, int32_t n, double thr_e, void* corrm, hipStream_t st) {
+  if (!corr || !corrm || n <= 0 || !(thr_e > 0.0) || ((uintptr_t)corrm & 15u) != 0) return SFM_EINVAL;
   const int npad = padded32(n);
-  corr_to_mfma_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, (uint4*)corrm,
-                                                               (float2*)((char*)corrm + (size_t)npad * 32));
+  corr_to_mfma_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, 1.0 / sqrt(uniform_k1(2.0 * thr_e * thr_e)),
+                                                               (uint4*)corrm, (float2*)((char*)corrm + (size_t)npad * 32));
   return check_launch();
 }
 
-int sfm_corr_to_mfma(const double* corr, int32_t n, void* corrm, void* stream) {
+int sfm_corr_to_mfma(const double* corr, int32_t n, double thr_e, void* corrm, void* stream) {
   clear_stale_error();
-  return launch_corr_to_mfma(corr, n, corrm, (hipStream_t)stream);
+  return launch_corr_to_mfma(corr, n, thr_e, corrm, (hipStream_t)stream);
 }
 
 static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
@@ -1818,7 +1822,7 @@ int sfm_eh_best_submit(const double* corr, const float* corr32, int32_t n, const
   hipStream_t st = (hipStream_t)stream;
   // level 1: float32 bounds for every hypothesis, leaders, their exact counts, candidate lists
   if (loose == 2) {
-    SFM_TRY(launch_corr_to_mfma(corr, n, w.corrm, st));
+    SFM_TRY(launch_corr_to_mfma(corr, n, thr_e, w.corrm, st));
     SFM_TRY(launch_eh_upper_mfma(corr, w.corrm, n, idx, nb, thr_e, thr_h, xmax, safety, w.up_e, w.up_h, st));
   } else {
     SFM_TRY(launch_eh_upper(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, loose, w.up_e, w.up_h, st));

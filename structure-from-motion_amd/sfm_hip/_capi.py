@@ -52,7 +52,7 @@ _SIGS = {
     "sfm_lm_translation_f64": (_c.c_int, [_P, _P, _P, _c.c_int32, _P, _c.c_int32, _c.c_double, _P, _P, _P, _P]),
     "sfm_index_sets_i32": (_c.c_int, [_c.c_uint64, _c.c_uint64, _c.c_int64, _c.c_int32, _c.c_int32, _P, _P]),
     "sfm_corr_mfma_bytes": (_c.c_int64, [_c.c_int32]),
-    "sfm_corr_to_mfma": (_c.c_int, [_P, _c.c_int32, _P, _P]),
+    "sfm_corr_to_mfma": (_c.c_int, [_P, _c.c_int32, _c.c_double, _P, _P]),
     "sfm_eh_upper_mfma_f32": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _P, _P, _P]),
     "sfm_t_ransac_mixed_workspace_bytes": (_c.c_int64, [_P, _c.c_int32]),
     "sfm_t_ransac_mixed": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _P, _c.c_int64, _P, _P, _P, _P]),

@@ -94,13 +94,14 @@ def eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, out=None, one_si
     return ue, uh
 
 
-def corr_to_mfma(corr):
-    """Match-side operands of the matrix-core pre-filter (bf16 piece vectors of (x1, y1, 1) + float32 (x2, y2))."""
+def corr_to_mfma(corr, thr_e):
+    """Match-side operands of the matrix-core pre-filter for the epipolar threshold thr_e (bf16 piece vectors of
+    (x1, y1, 1) + float32 (x2, y2) divided by the square root of the slackened threshold constant)."""
     torch = C.torch_cuda()
     lib = C.load_library()
     n = corr.shape[0]
     corrm = _empty((int(lib.sfm_corr_mfma_bytes(n)),), torch.uint8)
-    C.check(lib.sfm_corr_to_mfma(C.dptr(corr), n, C.dptr(corrm), C.stream_ptr()))
+    C.check(lib.sfm_corr_to_mfma(C.dptr(corr), n, float(thr_e), C.dptr(corrm), C.stream_ptr()))
     return corrm
 
 

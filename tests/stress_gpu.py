@@ -42,7 +42,7 @@ def main(n_cfg):
         corr_h = ops.pack_corr(x1n, x2n)
         corr = _capi.dev(corr_h)
         c32 = ops.corr_to_f32(corr)
-        cm = ops.corr_to_mfma(corr)
+        cm = ops.corr_to_mfma(corr, thr)
         xmax = float(np.abs(corr_h).max())
         idx = ops.index_sets(c, 0, B, n)
         ce, ch = ops.eh_score(corr, idx, thr, 3 * thr)

@@ -363,7 +363,7 @@ def test_matrix_core_bounds_are_upper_bounds(ops, dev, n, B, inl, seed):
     idx = ops.index_sets(seed, 0, B, n)
     thr = 1.0 / sc["K"][0][0]
     ce, ch = ops.eh_score(corr, idx, thr, 3 * thr)
-    me, mh = ops.eh_upper_mfma(corr, ops.corr_to_mfma(corr), idx, thr, 3 * thr, xmax)
+    me, mh = ops.eh_upper_mfma(corr, ops.corr_to_mfma(corr, thr), idx, thr, 3 * thr, xmax)
     ve, vh = ops.eh_upper(corr, ops.corr_to_f32(corr), idx, thr, 3 * thr, xmax, one_sided=True)
     assert int((me < ce).sum()) == 0 and int((mh < ch).sum()) == 0
     assert float((me - ce).double().mean()) <= float((ve - ce).double().mean()) * 1.2 + 0.5
