@@ -366,6 +366,7 @@ __host__ __device__ inline double uniform_k1(double two_thr_e2) { return two_thr
 __global__ __launch_bounds__(kBlock) void corr_to_mfma_kernel(const double4* __restrict__ corr, int n, int npad, double inv_sqrt_k1,
                                                               uint4* __restrict__ pieces, float2* __restrict__ xy) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) *reinterpret_cast<double*>(xy + npad) = inv_sqrt_k1;  // tag: which threshold these operands were prepared for
   if (j >= npad) return;
   if (j < n) {
     const double4 c = corr[j];
@@ -517,7 +518,10 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
   }
   // lane L reports hypothesis L = 32*half + col, the one it solved itself
   const unsigned ok = fin[wave][lane];
-  const int oute = (ok & 1u) ? (half ? se[1] : se[0]) : 0, outh = (ok & 2u) ? (half ? sh[1] : sh[0]) : 0;
+  int oute = (ok & 1u) ? (half ? se[1] : se[0]) : 0, outh = (ok & 2u) ? (half ? sh[1] : sh[0]) : 0;
+  // operands prepared for another threshold cannot give valid bounds: report the trivial bound (all matches of this split)
+  const int npad_all = ((n + 31) / 32) * 32;
+  if (*reinterpret_cast<const double*>(xy + npad_all) != inv_sqrt_k1) oute = outh = max(0, min(n, t1 * 32) - t0 * 32);
   if (gid < nb) {
     if (use_atomics) {
       atomicAdd(up_e + gid, oute);
@@ -1684,7 +1688,7 @@ int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const i
 // match-side operands of the matrix-core pre-filter: [npad][32 B] piece vectors, then [npad] float2
 static inline int padded32(int n) { return (n + 31) & ~31; }
 
-int64_t sfm_corr_mfma_bytes(int32_t n) { return n <= 0 ? 0 : (int64_t)padded32(n) * 40; }
+int64_t sfm_corr_mfma_bytes(int32_t n) { return n <= 0 ? 0 : (int64_t)padded32(n) * 40 + 16; }
 
 static int launch_corr_to_mfma(const double* corr, int32_t n, double thr_e, void* corrm, hipStream_t st) {
   if (!corr || !corrm || n <= 0 || !(thr_e > 0.0) || ((uintptr_t)corrm & 15u) != 0) return SFM_EINVAL;
@@ -1797,7 +1801,7 @@ inline size_t carve(char* base, int64_t nb, int32_t n, BestWs* w) {
   w->rows = (int32_t*)take(sizeof(int32_t) * 12 * 2 * kCandCap);
   w->sc_e = (int*)take(sizeof(int) * 2 * kCandCap);
   w->sc_h = (int*)take(sizeof(int) * 2 * kCandCap);
-  w->corrm = take((size_t)((n + 31) & ~31) * 40);
+  w->corrm = take((size_t)((n + 31) & ~31) * 40 + 16);
   w->spec_ids = (int32_t*)take(sizeof(int32_t) * 2 * kSpecCap);
   w->pending = (BestPending*)take(sizeof(BestPending));
   return off;

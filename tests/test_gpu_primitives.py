@@ -492,3 +492,15 @@ def test_mixed_eh_scoring_on_the_threshold_and_degenerate_inputs(ops, dev):
     a = ops.eh_score(same, idx2, 4e-4, 1.2e-3)
     b = ops.eh_score_mixed(same, idx2, 4e-4, 1.2e-3, 0.2)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_matrix_core_bounds_with_operands_of_another_threshold_stay_valid(ops, dev):
+    """The match-side operands carry the threshold they were prepared for; with any other threshold the kernel reports the
+    trivial bound (every match) instead of a wrong one."""
+    sc, x1, x2 = scene(n=700, inl=0.5, pl=0.5, seed=2)
+    corr_h = ops.pack_corr(x1, x2)
+    corr = dev(corr_h)
+    idx = ops.index_sets(2, 0, 3000, 700)
+    thr = 1.0 / sc["K"][0][0]
+    me, mh = ops.eh_upper_mfma(corr, ops.corr_to_mfma(corr, 2 * thr), idx, thr, 3 * thr, float(np.abs(corr_h).max()))
+    assert int(me.min()) == 700 and int(mh.min()) == 700
