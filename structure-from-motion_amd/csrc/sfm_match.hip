@@ -7,7 +7,8 @@
 // correctly rounded square root of that integer.  Nothing here depends on a summation order.
 //
 // Layout: a wave owns 32 query descriptors (A fragments live in registers for the whole kernel)
-// and walks the train descriptors in tiles of 32 (B fragments straight from global memory / L2).
+// and walks the train descriptors in tiles of 32 (B fragments from LDS, where the four waves of a
+// workgroup share each staged tile).
 // In the 32x32 accumulator layout a lane holds one train column and 16 query rows, so the running
 // best / second-best per (lane, row slot) needs no cross-lane traffic inside the loop; the 32
 // column classes are merged once at the end with wave shuffles.  Both MFMA operands are loaded
@@ -65,11 +66,17 @@ __device__ __forceinline__ int med3i(int a, int b, int c) { return max(min(a, b)
 __global__ __launch_bounds__(kBlock) void knn2_kernel(const int8_t* __restrict__ q8, int nq, const int8_t* __restrict__ t8,
                                                       const int32_t* __restrict__ tnorm, int nt, int tiles_per_split,
                                                       int4* __restrict__ partial) {
+  // Train tiles (32 descriptors x 128 B each) are shared by the four waves of the workgroup through LDS, kGroup tiles
+  // per barrier (the kernel would otherwise be bound by L2 bandwidth: every wave streams the whole train set); rows
+  // are padded to 144 B against bank conflicts.
+  constexpr int kGroup = 4;
+  __shared__ v4i tile[2][kGroup][32 * 9];
+  __shared__ int tile_norm[2][kGroup][32];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int qbase = (blockIdx.x * (kBlock / 64) + wave) * 32;
-  if (qbase >= nq) return;  // wave-uniform
+  const bool active = qbase < nq;  // wave-uniform; inactive waves still stage tiles and meet the barriers
   const int ntiles = (nt + 31) / 32;
   const int tile_begin = blockIdx.y * tiles_per_split;
   const int tile_end = min(ntiles, tile_begin + tiles_per_split);
@@ -85,25 +92,62 @@ __global__ __launch_bounds__(kBlock) void knn2_kernel(const int8_t* __restrict__
 #pragma unroll
   for (int i = 0; i < 16; ++i) { b1[i] = kFloor; b2[i] = kFloor; t1[i] = 0; }
 
-  for (int tt = tile_begin; tt < tile_end; ++tt) {
-    const int col = tt * 32 + r;
-    const int colc = min(col, nt - 1);
-    const v4i* p = reinterpret_cast<const v4i*>(t8 + (long long)colc * kDim + 64 * h);
-    v4i b[4];
+  // staging: thread t fetches the 16 bytes `part` of train column sc of each tile of the group
+  const int sc = threadIdx.x >> 3, part = threadIdx.x & 7;
+  v4i stage[kGroup];
+  int stage_norm[kGroup];
+  auto fetch = [&](int tt0) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) b[s] = p[s];
-    const int ntn = -(col < nt ? tnorm[colc] : kInvalidNorm);
-    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[s], acc, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int e = (acc[i] << 1) + ntn;
-      t1[i] = e > b1[i] ? tt : t1[i];
-      b2[i] = med3i(b1[i], b2[i], e);
-      b1[i] = max(b1[i], e);
+    for (int g = 0; g < kGroup; ++g) {
+      const int col = (tt0 + g) * 32 + sc;
+      const int colc = min(col, nt - 1);  // tiles past the end repeat the last descriptor with an invalid norm
+      stage[g] = *reinterpret_cast<const v4i*>(t8 + (long long)colc * kDim + 16 * part);
+      stage_norm[g] = col < nt ? tnorm[colc] : kInvalidNorm;
     }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g) {
+      tile[buf][g][sc * 9 + part] = stage[g];
+      if (part == 0) tile_norm[buf][g][sc] = stage_norm[g];
+    }
+  };
+  if (tile_begin < tile_end) {
+    fetch(tile_begin);
+    commit(0);
   }
+  __syncthreads();
+  int buf = 0;
+  for (int tt0 = tile_begin; tt0 < tile_end; tt0 += kGroup) {
+    const bool more = tt0 + kGroup < tile_end;
+    if (more) fetch(tt0 + kGroup);  // in flight while this group is scored
+    if (active) {
+#pragma unroll
+      for (int g = 0; g < kGroup; ++g) {
+        const int tt = tt0 + g;
+        if (tt < tile_end) {  // uniform
+          v4i b[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b[s] = tile[buf][g][r * 9 + 4 * h + s];
+          const int ntn = -tile_norm[buf][g][r];
+          v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[s], acc, 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int e = (acc[i] << 1) + ntn;
+            t1[i] = e > b1[i] ? tt : t1[i];
+            b2[i] = med3i(b1[i], b2[i], e);
+            b1[i] = max(b1[i], e);
+          }
+        }
+      }
+    }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (!active) return;
 
   // merge the 32 column classes of each half-wave: key = (e + 2^30, ~train index), the largest key is the
   // closest descriptor with the lowest index on ties; only the distance of the runner-up is kept.
