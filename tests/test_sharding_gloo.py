@@ -73,3 +73,25 @@ def test_merge_matches_single_rank_first_maximum(tmp_path, world):
         for k, counts in enumerate(counts_all):
             c, i = unpack_key(got[k])
             assert (c, i) == (int(counts.max()), int(np.argmax(counts)))
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_in_process_shard_and_merge_names_the_single_rank_winner(world):
+    """The index partition + packed-max merge without any communication library: for every world size the merged key
+    is the first maximum of the whole range, also when the maximum occurs in several shards."""
+    import numpy as np
+
+    from sfm_hip import sharding
+
+    rng = np.random.default_rng(world)
+    for total in (1000, 12345, 8):
+        counts = rng.integers(0, 50, size=total)
+        counts[rng.integers(0, total, size=5)] = 77  # tied maxima scattered over the range
+        want = (int(counts.max()), int(np.argmax(counts)))
+        keys = []
+        for r in range(world):
+            lo, hi = sharding.shard_range(total, r, world)
+            if hi > lo:
+                local = counts[lo:hi]
+                keys.append(sharding.pack_key(int(local.max()), lo + int(np.argmax(local))))
+        assert sharding.unpack_key(max(keys)) == want
