@@ -220,6 +220,11 @@ int64_t sfm_corr_mfma_bytes(int32_t n);
 int sfm_corr_to_mfma(const double* corr, int32_t n, double thr_e, void* corrm, void* stream);
 int sfm_eh_upper_mfma_f32(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e,
                           double thr_h, double xmax, double safety, int32_t* up_e, int32_t* up_h, void* stream);
+/* Measurement aid: the same launch with only the epipolar test (part = 1: the inner loop of
+ * src/ransac_algorithm.py:98-102) or only the transfer test (part = 2: :120-121); the other output is zero. */
+int sfm_eh_upper_mfma_part_f32(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e,
+                               double thr_h, double xmax, double safety, int32_t part, int32_t* up_e, int32_t* up_h,
+                               void* stream);
 
 /* sfm_t_ransac_f64 with the bulk of the residual tests on the bf16 matrix cores + float32 and IDENTICAL counts:
  * dx, dy and thr*pz of src/estimate_translation.py:123-127 are bilinear in (hypothesis, correspondence) and come from

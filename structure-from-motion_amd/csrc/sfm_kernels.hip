@@ -384,6 +384,7 @@ __global__ __launch_bounds__(kBlock) void corr_to_mfma_kernel(const double4* __r
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
+template <bool kDoE, bool kDoH>
 __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
                                                                   const float2* __restrict__ xy, int n, const int32_t* __restrict__ idx,
                                                                   long long nb, double two_thr_e2, double thr_h2, double xmax, double safety,
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      {
+      if constexpr (kDoE) {
         const f32x16 l0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][0], zero, 0, 0, 0);
         const f32x16 l1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][1], zero, 0, 0, 0);
         const f32x16 l2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][2], zero, 0, 0, 0);
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
         }
         ce[k] += __popc(he[k] & vmask);
       }
-      {
+      if constexpr (kDoH) {
         const f32x16 hx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][3], zero, 0, 0, 0);
         const f32x16 hy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][4], zero, 0, 0, 0);
         const f32x16 hz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][5], zero, 0, 0, 0);
@@ -1704,7 +1705,7 @@ int sfm_corr_to_mfma(const double* corr, int32_t n, double thr_e, void* corrm, v
 }
 
 static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
-                                double xmax, double safety, int32_t* up_e, int32_t* up_h, hipStream_t st) {
+                                double xmax, double safety, int32_t* up_e, int32_t* up_h, hipStream_t st, int part = 0) {
   if (!corr || !corrm || !idx || !up_e || !up_h || n <= 0 || nb < 0 || ((uintptr_t)corrm & 15u) != 0) return SFM_EINVAL;
   if (!(xmax > 0.0 && xmax < 1.0e6 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
   if (nb == 0) return 0;
@@ -1721,9 +1722,19 @@ static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n
     e = hipMemsetAsync(up_h, 0, sizeof(int32_t) * nb, st);
     if (e != hipSuccess) return (int)e;
   }
-  eh_upper_mfma_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>(
-      (const double4*)corr, (const uint4*)corrm, (const float2*)((const char*)corrm + (size_t)npad * 32), n, idx, nb, 2.0 * thr_e * thr_e,
-      thr_h * thr_h, xmax, safety, up_e, up_h, tps, splits > 1);
+  const uint4* pieces = (const uint4*)corrm;
+  const float2* xy = (const float2*)((const char*)corrm + (size_t)npad * 32);
+  const dim3 grid((unsigned)tiles, splits);
+  const double ke = 2.0 * thr_e * thr_e, kh = thr_h * thr_h;
+  if (part == 1)  // measurement only: the epipolar half alone (up_h receives zeros)
+    eh_upper_mfma_kernel<true, false><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, ke, kh, xmax, safety, up_e, up_h, tps,
+                                                               splits > 1);
+  else if (part == 2)  // measurement only: the transfer half alone
+    eh_upper_mfma_kernel<false, true><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, ke, kh, xmax, safety, up_e, up_h, tps,
+                                                               splits > 1);
+  else
+    eh_upper_mfma_kernel<true, true><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, ke, kh, xmax, safety, up_e, up_h, tps,
+                                                              splits > 1);
   return check_launch();
 }
 
@@ -1731,6 +1742,13 @@ int sfm_eh_upper_mfma_f32(const double* corr, const void* corrm, int32_t n, cons
                           double xmax, double safety, int32_t* up_e, int32_t* up_h, void* stream) {
   clear_stale_error();
   return launch_eh_upper_mfma(corr, corrm, n, idx, nb, thr_e, thr_h, xmax, safety, up_e, up_h, (hipStream_t)stream);
+}
+
+int sfm_eh_upper_mfma_part_f32(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
+                               double xmax, double safety, int32_t part, int32_t* up_e, int32_t* up_h, void* stream) {
+  clear_stale_error();
+  if (part != 1 && part != 2) return SFM_EINVAL;
+  return launch_eh_upper_mfma(corr, corrm, n, idx, nb, thr_e, thr_h, xmax, safety, up_e, up_h, (hipStream_t)stream, part);
 }
 
 int64_t sfm_eh_score_mixed_workspace_bytes(int64_t nb, int32_t n) {

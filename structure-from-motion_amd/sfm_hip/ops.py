@@ -105,8 +105,9 @@ def corr_to_mfma(corr, thr_e):
     return corrm
 
 
-def eh_upper_mfma(corr, corrm, idx, thr_e, thr_h, xmax, safety=2.0, out=None):
-    """Loose float32 upper bounds like eh_upper(one_sided=True), with E x1 and H x1 on the bf16 matrix cores."""
+def eh_upper_mfma(corr, corrm, idx, thr_e, thr_h, xmax, safety=2.0, out=None, part=0):
+    """Loose float32 upper bounds like eh_upper(one_sided=True), with E x1 and H x1 on the bf16 matrix cores.
+    part=1 / 2 (measurement aid): only the epipolar / only the transfer test."""
     torch = C.torch_cuda()
     lib = C.load_library()
     nb = idx.shape[0]
@@ -115,6 +116,10 @@ def eh_upper_mfma(corr, corrm, idx, thr_e, thr_h, xmax, safety=2.0, out=None):
         uh = _empty((nb,), torch.int32)
     else:
         ue, uh = out
+    if part:
+        C.check(lib.sfm_eh_upper_mfma_part_f32(C.dptr(corr), C.dptr(corrm), corr.shape[0], C.dptr(idx), nb, float(thr_e), float(thr_h),
+                                               float(xmax), float(safety), int(part), C.dptr(ue), C.dptr(uh), C.stream_ptr()))
+        return ue, uh
     C.check(lib.sfm_eh_upper_mfma_f32(C.dptr(corr), C.dptr(corrm), corr.shape[0], C.dptr(idx), nb, float(thr_e), float(thr_h),
                                       float(xmax), float(safety), C.dptr(ue), C.dptr(uh), C.stream_ptr()))
     return ue, uh
