@@ -18,6 +18,17 @@
  *    essential-matrix solver, columns 8-11 the 4-point homography solver
  *    (src/ransac_algorithm.py:94 and :116 draw them in this order).
  *  - 3x3 matrices are row-major [9]; cameras are row-major 3x4 [12].
+ *  - Sample indices (`idx`, `row`) must lie in [0, n) (for the translation stage: in [0, points of that camera)).
+ *    The kernels clamp every index into that range before they use it, so a bad index cannot fault the GPU; the model
+ *    of such a hypothesis is then that of the clamped sample.  Only the record entry points reject a bad row.
+ *  - `xmax` parameters are a HINT: max |coordinate| over corr as far as the caller knows it (0 = unknown).  The
+ *    library measures the maximum itself while it prepares the match-side operands and uses the larger of the two, so
+ *    an understated hint cannot void a bound.  Matches with a NaN, infinite or absurdly large (>= 1e6) coordinate have
+ *    no usable bound: upper-bound entry points then return the trivial bound n, exact entry points evaluate every pair
+ *    in float64.  Negative or NaN hints are rejected.
+ *  - Thresholds follow the reference's comparisons: the epipolar test squares its threshold
+ *    (src/ransac_algorithm.py:102), so its sign is irrelevant; the transfer and the reprojection test compare a norm
+ *    with the threshold itself (:327, src/estimate_translation.py:127), so a non-positive one admits no match.
  */
 #ifndef SFM_HIP_H
 #define SFM_HIP_H
@@ -41,14 +52,16 @@ int sfm_hip_abi_version(void);
 int sfm_eh_score_f64(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
                      int32_t* count_e, int32_t* count_h, void* stream);
 
-/* float32 copy of the correspondences for sfm_eh_upper_f32: corr32 float[n][4]. */
+/* float32 copy of the correspondences for sfm_eh_upper_f32 and sfm_eh_best: corr32 = float[n + 1][4], 16-byte aligned,
+ * sfm_corr_f32_bytes(n) bytes: the n matches and one trailer row whose first word is the measured max |coordinate|. */
+int64_t sfm_corr_f32_bytes(int32_t n);
 int sfm_corr_to_f32(const double* corr, int32_t n, float* corr32, void* stream);
 
 /* Float32 pre-filter for the same hypotheses: UPPER BOUNDS up_e/up_h (int32[nb]) of the counts
  * sfm_eh_score_f64 would return.  Models are solved in float64, scaled to max-abs 1, rounded to
  * float32 and scored against corr32 with upper-bound forms of the two tests whose slack is
- * derived per hypothesis from a float32 error bound; xmax = max |coordinate| over corr (>= 1 is
- * fine), safety >= 1 multiplies the bound (2 is the default of the Python layer).
+ * derived per hypothesis from a float32 error bound; xmax: hint, see Conventions (corr32 carries the
+ * measured value), safety >= 1 multiplies the bound (2 is the default of the Python layer).
  * one_sided != 0 selects cheaper, looser bounds: for E the symmetric test implies the one-sided
  * test "distance to the epipolar line in view 2 < sqrt(2) thr" (no E^T x2), for H the disc test
  * implies the per-component box test (no squares); 26 instead of 38 instructions per residual
@@ -95,7 +108,7 @@ int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_
 /* sfm_eh_score_f64 with the bulk of the residual tests on the bf16 matrix cores + float32 and IDENTICAL counts: the
  * rows E x1, E^T x2 and H x1 come from MFMAs of three-piece splits; a pair whose float32 test value lies inside the
  * rigorous error band around the threshold is re-evaluated with the float64 test inside the kernel.
- * xmax: max |coordinate| over corr.  workspace: sfm_eh_score_mixed_workspace_bytes(nb, n) bytes, 256-byte aligned. */
+ * xmax: hint, see Conventions.  workspace: sfm_eh_score_mixed_workspace_bytes(nb, n) bytes, 256-byte aligned. */
 int64_t sfm_eh_score_mixed_workspace_bytes(int64_t nb, int32_t n);
 int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax,
                        void* workspace, int64_t workspace_bytes, int32_t* count_e, int32_t* count_h, void* stream);
@@ -180,7 +193,9 @@ int sfm_pts_to_f32(const double* pts, int64_t m, float* pts32, void* stream);
 /* Float32 pre-filter of sfm_t_ransac_f64: UPPER BOUNDS up int32[ncam][nb] of the counts it would
  * compute (same arguments; T solved in float64, scored in float32 with a slack derived from the
  * float32 error bound).  rmax (HOST, double[ncam]): max |component of R X| per camera; xmax: max
- * |x|,|y| over all cameras; safety >= 1.  Use as sfm_eh_upper_f32: exact-score the leader, then
+ * |x|,|y| over all cameras; safety >= 1.  PRECONDITION (not checked, unlike the E/H entry points): rmax and xmax are
+ * true maxima; understated values void the bound.  sfm_t_ransac_mixed measures its maxima itself and is the
+ * entry point the package uses.  Use as sfm_eh_upper_f32: exact-score the leader, then
  * every hypothesis whose bound reaches its count (sfm_hip/ops.py:t_best). */
 int sfm_t_upper_f32(const double* pts, const float* pts32, const int64_t* cam_off, int32_t ncam, const int32_t* idx,
                     int64_t nb, double thr, const double* rmax, double xmax, double safety, int32_t* up, void* stream);

@@ -27,17 +27,22 @@ struct CamOffsets {
   int64_t off[kMaxCams + 1];
 };
 
+// Sample indices come from the caller: they are clamped into [0, n) so that a bad index can never become an
+// out-of-bounds read (the model of such a hypothesis is meaningless, as it would be in the reference's
+// `x1[:, inds]` with a wrapped negative index).
+__device__ __forceinline__ int clamp_index(int i, int n) { return min(max(i, 0), n - 1); }
+
 template <typename T>
-__device__ __forceinline__ void gather_samples(const double4* __restrict__ corr, const int32_t* __restrict__ row, T (&p8)[8][4],
+__device__ __forceinline__ void gather_samples(const double4* __restrict__ corr, int n, const int32_t* __restrict__ row, T (&p8)[8][4],
                                                T (&p4)[4][4]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const double4 c = corr[row[i]];
+    const double4 c = corr[clamp_index(row[i], n)];
     p8[i][0] = T(c.x); p8[i][1] = T(c.y); p8[i][2] = T(c.z); p8[i][3] = T(c.w);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const double4 c = corr[row[8 + i]];
+    const double4 c = corr[clamp_index(row[8 + i], n)];
     p4[i][0] = T(c.x); p4[i][1] = T(c.y); p4[i][2] = T(c.z); p4[i][3] = T(c.w);
   }
 }
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void eh_score_kernel(const double4* __restr
   double E[9], H[9];
   {
     double p8[8][4], p4[4][4];
-    gather_samples<double>(corr, idx + 12 * h, p8, p4);
+    gather_samples<double>(corr, n, idx + 12 * h, p8, p4);
     solve_E8<double>(p8, E);
     solve_H4<double>(p4, H);
   }
@@ -128,6 +133,29 @@ __device__ __forceinline__ float round_up_f32(double v) {
   return ((double)f < v) ? nextafterf(f, INFINITY) : f;
 }
 
+__device__ __forceinline__ unsigned f32_up_bits(double v) { return __float_as_uint(round_up_f32(v)); }
+
+// max |coordinate| over the matches, measured on the device: each lane folds its match into a float32 bit pattern
+// (rounded up; non-negative floats order like their bits and a NaN orders above infinity), one unsigned atomicMax per
+// wave.  Every lane of the wave must call this (the reduction shuffles across all 64 lanes); *dst starts at zero.
+__device__ __forceinline__ void publish_absmax(const double4& c, bool live, unsigned* __restrict__ dst) {
+  unsigned m = 0u;
+  if (live) m = max(max(f32_up_bits(fabs(c.x)), f32_up_bits(fabs(c.y))), max(f32_up_bits(fabs(c.z)), f32_up_bits(fabs(c.w))));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(dst, m);
+}
+
+// The coordinate bound the error analysis uses: the larger of the caller's hint and the measured maximum, so an
+// understated hint cannot void a bound.  Infinity = unusable (a NaN or absurdly large coordinate): callers then report
+// trivial bounds or evaluate in float64.
+__device__ __forceinline__ double usable_xmax(double hint, unsigned measured_bits) {
+  const double m = (double)__uint_as_float(measured_bits);
+  double x = (hint > m) ? hint : m;  // a NaN measurement stays NaN
+  if (x < 0x1.0p-20) x = 0x1.0p-20;
+  return (x < 1.0e6) ? x : (double)INFINITY;
+}
+
 struct UpperModel {
   float E[9], H[9];
   float kp_e, c2_e, T_h, c1_h, c0_h;
@@ -136,11 +164,11 @@ struct UpperModel {
 };
 
 // solves hypothesis h in float64 and derives the float32 models and slack constants
-__device__ __forceinline__ void solve_upper_model(const double4* __restrict__ corr, const int32_t* __restrict__ row, double two_thr_e2,
+__device__ __forceinline__ void solve_upper_model(const double4* __restrict__ corr, int n, const int32_t* __restrict__ row, double two_thr_e2,
                                                   double thr_h2, double xmax, double safety, UpperModel& m) {
   double Ed[9], Hd[9], A[9];
   double p8[8][4], p4[4][4];
-  gather_samples<double>(corr, row, p8, p4);
+  gather_samples<double>(corr, n, row, p8, p4);
   solve_E8<double>(p8, Ed);
   solve_H4<double>(p4, Hd);
   to_unit_f32(Ed, m.E, A);
@@ -188,8 +216,9 @@ __global__ __launch_bounds__(kBlock) void eh_upper_lds_kernel(const double4* __r
   __shared__ float4 tile[2][kTilePoints];
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long h = gid < nb ? gid : nb - 1;
+  const double xm = usable_xmax(xmax, __float_as_uint(corr32[n].x));
   UpperModel um;
-  solve_upper_model(corr, idx + 12 * h, two_thr_e2, thr_h2, xmax, safety, um);
+  solve_upper_model(corr, n, idx + 12 * h, two_thr_e2, thr_h2, xm, safety, um);
   const float(&E)[9] = um.E;
   const float(&H)[9] = um.H;
   const float kp_e = um.kp_e, c2_e = um.c2_e, T_h = um.T_h, c1_h = um.c1_h, c0_h = um.c0_h;
@@ -230,6 +259,7 @@ __global__ __launch_bounds__(kBlock) void eh_upper_lds_kernel(const double4* __r
     __syncthreads();
     buf ^= 1;
   }
+  if (!(xm < 1.0e6)) ce = ch = max(0, j1 - j0);  // no usable coordinate bound: the trivial bound
   if (gid < nb) {
     if (use_atomics) {
       atomicAdd(up_e + gid, ce);
@@ -248,8 +278,9 @@ __global__ __launch_bounds__(kBlock) void eh_upper_kernel(const double4* __restr
                                                           int points_per_split, int use_atomics) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long h = gid < nb ? gid : nb - 1;
+  const double xm = usable_xmax(xmax, __float_as_uint(corr32[n].x));
   UpperModel um;
-  solve_upper_model(corr, idx + 12 * h, two_thr_e2, thr_h2, xmax, safety, um);
+  solve_upper_model(corr, n, idx + 12 * h, two_thr_e2, thr_h2, xm, safety, um);
   const float(&E)[9] = um.E;
   const float(&H)[9] = um.H;
   const float kp_e = um.kp_e, c2_e = um.c2_e, T_h = um.T_h, c1_h = um.c1_h, c0_h = um.c0_h;
@@ -269,6 +300,7 @@ __global__ __launch_bounds__(kBlock) void eh_upper_kernel(const double4* __restr
       ch += transfer_upper_f32(H, p.x, p.y, p.z, p.w, T_h, c1_h, c0_h) ? 1 : 0;
     }
   }
+  if (!(xm < 1.0e6)) ce = ch = max(0, j1 - j0);  // no usable coordinate bound: the trivial bound
   if (gid < nb) {
     if (use_atomics) {
       atomicAdd(up_e + gid, ce);
@@ -362,24 +394,26 @@ constexpr double kGe = 0x1.0p-18, kGh = 0x1.0p-18, kMuE = 0.025;
 __host__ __device__ inline double uniform_k1(double two_thr_e2) { return two_thr_e2 * (1.0 + kMuE) * (1.0 + 32.0 * kEps32); }
 
 // Match-side operands for the matrix-core pre-filter: pieces[npad][2] (the 16 bf16 of (x1, y1, 1)) and
-// xy[npad] = float32 (x2, y2) / sqrt(k1); npad = n rounded up to 32 (the scoring kernel masks the padding).
+// xy[npad] = float32 (x2, y2) / sqrt(k1); npad = n rounded up to 32 (the scoring kernel masks the padding); then a
+// 16-byte trailer: the threshold tag (double) and the measured max |coordinate| (float32 bits).
 __global__ __launch_bounds__(kBlock) void corr_to_mfma_kernel(const double4* __restrict__ corr, int n, int npad, double inv_sqrt_k1,
                                                               uint4* __restrict__ pieces, float2* __restrict__ xy) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j == 0) *reinterpret_cast<double*>(xy + npad) = inv_sqrt_k1;  // tag: which threshold these operands were prepared for
-  if (j >= npad) return;
+  double4 c = make_double4(0.0, 0.0, 0.0, 0.0);
   if (j < n) {
-    const double4 c = corr[j];
+    c = corr[j];
     uint4 lo, hi;
     pack_pieces(c.x, c.y, 1.0, false, lo, hi);
     pieces[2 * j] = lo;
     pieces[2 * j + 1] = hi;
     xy[j] = make_float2((float)(c.z * inv_sqrt_k1), (float)(c.w * inv_sqrt_k1));
-  } else {
+  } else if (j < npad) {
     pieces[2 * j] = make_uint4(0, 0, 0, 0);
     pieces[2 * j + 1] = make_uint4(0, 0, 0, 0);
     xy[j] = make_float2(0.0f, 0.0f);
   }
+  publish_absmax(c, j < n, reinterpret_cast<unsigned*>(xy + npad) + 2);  // behind the tag; zeroed by the launcher
 }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
@@ -397,12 +431,14 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
   const double inv_sqrt_k1 = 1.0 / sqrt(uniform_k1(two_thr_e2));
+  const int npad_all = ((n + 31) / 32) * 32;
+  const double xm = usable_xmax(xmax, reinterpret_cast<const unsigned*>(xy + npad_all)[2]);
   {
     double Ed[9], Hd[9], A[9];
     float unused[9];
     {
       double p8[8][4], p4[4][4];
-      gather_samples<double>(corr, idx + 12 * hyp, p8, p4);
+      gather_samples<double>(corr, n, idx + 12 * hyp, p8, p4);
       solve_E8<double>(p8, Ed);
       solve_H4<double>(p4, Hd);
     }
@@ -419,9 +455,9 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
     }
     double inv = to_unit_f32(Ed, unused, A);
     {
-      const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
+      const double R0 = xm * (A[0] + A[1]) + A[2], R1 = xm * (A[3] + A[4]) + A[5], R2 = xm * (A[6] + A[7]) + A[8];
       // |s - s_true|: errors of l0, l1, l2 carried through s = l0 x2 + l1 y2 + l2, float32 rounding of x2, y2 and of the two fmas
-      const double Es = (kEpsMfma + 4.0 * kEps32) * (xmax * (R0 + R1) + R2);
+      const double Es = (kEpsMfma + 4.0 * kEps32) * (xm * (R0 + R1) + R2);
       // |L - L_true|, L = |(l0, l1)|: errors of l0 and l1 plus the float32 evaluation of l0^2 + l1^2
       const double eL = (kEpsMfma + 2.0 * kEps32) * (R0 + R1);
       const double G = safety * (Es + sqrt(two_thr_e2) * eL);
@@ -434,9 +470,9 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
     }
     inv = to_unit_f32(Hd, unused, A);
     {
-      const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
+      const double R0 = xm * (A[0] + A[1]) + A[2], R1 = xm * (A[3] + A[4]) + A[5], R2 = xm * (A[6] + A[7]) + A[8];
       const double ez = kEpsMfma * R2;
-      const double Dx = (kEpsMfma + 3.0 * kEps32) * (R0 + xmax * R2), Dy = (kEpsMfma + 3.0 * kEps32) * (R1 + xmax * R2);
+      const double Dx = (kEpsMfma + 3.0 * kEps32) * (R0 + xm * R2), Dy = (kEpsMfma + 3.0 * kEps32) * (R1 + xm * R2);
       const double G = safety * (sqrt(thr_h2) * ez + Dx + Dy);
       inv *= kGh / G;
     }
@@ -520,9 +556,9 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
   // lane L reports hypothesis L = 32*half + col, the one it solved itself
   const unsigned ok = fin[wave][lane];
   int oute = (ok & 1u) ? (half ? se[1] : se[0]) : 0, outh = (ok & 2u) ? (half ? sh[1] : sh[0]) : 0;
-  // operands prepared for another threshold cannot give valid bounds: report the trivial bound (all matches of this split)
-  const int npad_all = ((n + 31) / 32) * 32;
-  if (*reinterpret_cast<const double*>(xy + npad_all) != inv_sqrt_k1) oute = outh = max(0, min(n, t1 * 32) - t0 * 32);
+  // operands prepared for another threshold, or matches without a usable coordinate bound, cannot give valid bounds:
+  // report the trivial bound (all matches of this split)
+  if (*reinterpret_cast<const double*>(xy + npad_all) != inv_sqrt_k1 || !(xm < 1.0e6)) oute = outh = max(0, min(n, t1 * 32) - t0 * 32);
   if (gid < nb) {
     if (use_atomics) {
       atomicAdd(up_e + gid, oute);
@@ -549,18 +585,19 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
 __global__ __launch_bounds__(kBlock) void corr_to_mfma2_kernel(const double4* __restrict__ corr, int n, int npad, uint4* __restrict__ pieces,
                                                                float2* __restrict__ xy) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= npad) return;
   uint4* out = pieces + 4 * (long long)j;
+  double4 c = make_double4(0.0, 0.0, 0.0, 0.0);
   if (j < n) {
-    const double4 c = corr[j];
+    c = corr[j];
     pack_pieces(c.x, c.y, 1.0, false, out[0], out[1]);
     pack_pieces(c.z, c.w, 1.0, false, out[2], out[3]);
     xy[j] = make_float2((float)c.z, (float)c.w);
-  } else {
+  } else if (j < npad) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[i] = make_uint4(0, 0, 0, 0);
     xy[j] = make_float2(0.0f, 0.0f);
   }
+  publish_absmax(c, j < n, reinterpret_cast<unsigned*>(xy + npad));  // 16-byte trailer, zeroed by the launcher
 }
 
 __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
@@ -575,6 +612,8 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
   const double safety = 2.0;
+  const double xm = usable_xmax(xmax, *reinterpret_cast<const unsigned*>(xy + ((n + 31) / 32) * 32));
+  const bool all_f64 = !(xm < 1.0e6);  // no usable coordinate bound: every pair takes the float64 test
   float ca_own, cb_own, c1_own, c0_own;
   double Ed[9], Hd[9];
   {
@@ -582,7 +621,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
     float unused[9];
     {
       double p8[8][4], p4[4][4];
-      gather_samples<double>(corr, idx + 12 * hyp, p8, p4);
+      gather_samples<double>(corr, n, idx + 12 * hyp, p8, p4);
       solve_E8<double>(p8, Ed);
       solve_H4<double>(p4, Hd);
     }
@@ -597,9 +636,9 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
     }
     double inv = to_unit_f32(Ed, unused, A);
     {
-      const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
-      const double C0 = xmax * (A[0] + A[3]) + A[6], C1 = xmax * (A[1] + A[4]) + A[7];
-      const double Es = (kEpsMfma + 4.0 * kEps32) * (xmax * (R0 + R1) + R2);
+      const double R0 = xm * (A[0] + A[1]) + A[2], R1 = xm * (A[3] + A[4]) + A[5], R2 = xm * (A[6] + A[7]) + A[8];
+      const double C0 = xm * (A[0] + A[3]) + A[6], C1 = xm * (A[1] + A[4]) + A[7];
+      const double Es = (kEpsMfma + 4.0 * kEps32) * (xm * (R0 + R1) + R2);
       const double eL = (kEpsMfma + 2.0 * kEps32) * (R0 + R1 + C0 + C1);
       const double rk = sqrt(two_thr_e2);
       const double G = safety * (Es + rk * eL);
@@ -614,9 +653,9 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
       pack_pieces(Ed[v] * inv, Ed[3 + v] * inv, Ed[6 + v] * inv, true, bstage[wave][lane][3 + v][0], bstage[wave][lane][3 + v][1]);
     inv = to_unit_f32(Hd, unused, A);
     {
-      const double R0 = xmax * (A[0] + A[1]) + A[2], R1 = xmax * (A[3] + A[4]) + A[5], R2 = xmax * (A[6] + A[7]) + A[8];
+      const double R0 = xm * (A[0] + A[1]) + A[2], R1 = xm * (A[3] + A[4]) + A[5], R2 = xm * (A[6] + A[7]) + A[8];
       const double rt = sqrt(thr_h2);
-      const double Dx = (kEpsMfma + 3.0 * kEps32) * (R0 + xmax * R2), Dy = (kEpsMfma + 3.0 * kEps32) * (R1 + xmax * R2);
+      const double Dx = (kEpsMfma + 3.0 * kEps32) * (R0 + xm * R2), Dy = (kEpsMfma + 3.0 * kEps32) * (R1 + xm * R2);
       const double eq = rt * (kEpsMfma + 2.0 * kEps32) * R2;
       const double e = safety * (Dx + Dy + eq);
       c1_own = round_up_f32(4.0 * e + 13.0 * kEps32 * rt * R2 * 1.001);
@@ -693,7 +732,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
           const float band = fma(ca[k], __builtin_amdgcn_sqrtf(P * S), fma(cb[k], S, fma(cc, P, 1.0e-36f)));  // raw v_sqrt_f32: 1 ulp, inside the margin of ca
           hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(d) - band), 31);  // < 0 <=> the float32 sign is not trusted
         }
-        amb_e = hamb & vmask;
+        amb_e = all_f64 ? vmask : (hamb & vmask);
         ce[k] += __popc(hneg & vmask & ~amb_e);
       }
       {
@@ -710,7 +749,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
           hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d), 31);
           hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(d) - fma(c1[k], fabsf(q), c0[k])), 31);
         }
-        amb_h = hamb & vmask;
+        amb_h = all_f64 ? vmask : (hamb & vmask);
         ch[k] += __popc(hneg & vmask & ~amb_h);
       }
       if (amb_e | amb_h) {
@@ -761,20 +800,22 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
 
 __global__ __launch_bounds__(kBlock) void corr_to_f32_kernel(const double4* __restrict__ corr, int n, float4* __restrict__ corr32) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  double4 c = make_double4(0.0, 0.0, 0.0, 0.0);
   if (j < n) {
-    const double4 c = corr[j];
+    c = corr[j];
     corr32[j] = make_float4((float)c.x, (float)c.y, (float)c.z, (float)c.w);
   }
+  publish_absmax(c, j < n, reinterpret_cast<unsigned*>(corr32 + n));  // trailer row n, zeroed by the launcher
 }
 
-__global__ __launch_bounds__(kBlock) void eh_models_kernel(const double4* __restrict__ corr, const int32_t* __restrict__ idx, long long nb,
+__global__ __launch_bounds__(kBlock) void eh_models_kernel(const double4* __restrict__ corr, int n, const int32_t* __restrict__ idx, long long nb,
                                                            double* __restrict__ F_out, double* __restrict__ E_out,
                                                            double* __restrict__ H_out) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long h = gid < nb ? gid : nb - 1;
   double F[9], E[9], H[9];
   double p8[8][4], p4[4][4];
-  gather_samples<double>(corr, idx + 12 * h, p8, p4);
+  gather_samples<double>(corr, n, idx + 12 * h, p8, p4);
   solve_E8<double>(p8, E, F);
   solve_H4<double>(p4, H);
   if (gid < nb) {
@@ -810,10 +851,10 @@ struct RowArg {
   int32_t v[12];
 };
 
-__global__ void models_from_row_kernel(const double4* __restrict__ corr, RowArg row, double* __restrict__ E_out, double* __restrict__ H_out) {
+__global__ void models_from_row_kernel(const double4* __restrict__ corr, int n, RowArg row, double* __restrict__ E_out, double* __restrict__ H_out) {
   double E[9], H[9];
   double p8[8][4], p4[4][4];
-  gather_samples<double>(corr, row.v, p8, p4);
+  gather_samples<double>(corr, n, row.v, p8, p4);
   solve_E8<double>(p8, E);
   solve_H4<double>(p4, H);
   if (threadIdx.x == 0) {
@@ -983,11 +1024,11 @@ __global__ __launch_bounds__(kBlock) void pack_points_kernel(const double* __res
   pts[6LL * j + 5] = x[2LL * m + j];
 }
 
-__device__ __forceinline__ void load_t_sample(const double* __restrict__ pts, const int32_t* __restrict__ pair, double (&x)[2][3],
+__device__ __forceinline__ void load_t_sample(const double* __restrict__ pts, int m, const int32_t* __restrict__ pair, double (&x)[2][3],
                                               double (&r)[2][3]) {
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const double* p = pts + 6LL * pair[k];
+    const double* p = pts + 6LL * clamp_index(pair[k], m);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       r[k][i] = p[i];
@@ -1009,7 +1050,7 @@ __global__ __launch_bounds__(kBlock) void t_score_kernel(const double* __restric
   double T[3];
   {
     double x[2][3], r[2][3];
-    load_t_sample(pts, pair, x, r);
+    load_t_sample(pts, m, pair, x, r);
     solve_T2<double>(x, r, pair[0] == pair[1], T);
   }
   const int j0 = blockIdx.z * points_per_split;
@@ -1029,12 +1070,12 @@ __global__ __launch_bounds__(kBlock) void t_score_kernel(const double* __restric
   }
 }
 
-__global__ __launch_bounds__(kBlock) void t_models_kernel(const double* __restrict__ pts, const int32_t* __restrict__ idx, long long nb,
+__global__ __launch_bounds__(kBlock) void t_models_kernel(const double* __restrict__ pts, int m, const int32_t* __restrict__ idx, long long nb,
                                                           double* __restrict__ T_out) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= nb) return;
   double x[2][3], r[2][3], T[3];
-  load_t_sample(pts, idx + 2 * gid, x, r);
+  load_t_sample(pts, m, idx + 2 * gid, x, r);
   solve_T2<double>(x, r, idx[2 * gid] == idx[2 * gid + 1], T);
 #pragma unroll
   for (int i = 0; i < 3; ++i) T_out[3 * gid + i] = T[i];
@@ -1062,7 +1103,7 @@ __global__ __launch_bounds__(kBlock) void t_upper_kernel(const double* __restric
   float Tf[3], Tthr, c1, c0;
   {
     double T[3], x[2][3], r[2][3];
-    load_t_sample(pts, pair, x, r);
+    load_t_sample(pts, m, pair, x, r);
     solve_T2<double>(x, r, pair[0] == pair[1], T);
 #pragma unroll
     for (int i = 0; i < 3; ++i) Tf[i] = (float)T[i];
@@ -1144,8 +1185,6 @@ __device__ __forceinline__ void pack_t_vector(bool lead_ones, double lead, bool 
   pack16(e, lo, hi);
 }
 
-__device__ __forceinline__ unsigned f32_up_bits(double v) { return __float_as_uint(round_up_f32(v)); }
-
 // grid = (padded point blocks, cameras).  pieces[P][3][2]: the match-side vectors of dx, dy and q;
 // maxima[cam][4] = max |rx - u rz|, |ry - v rz|, |rz|, max(|u|, |v|) as float32 bit patterns (rounded up).
 __global__ __launch_bounds__(kBlock) void t_prep_mfma_kernel(const double* __restrict__ pts_all, CamOffsets offs, CamPad pads, double thr,
@@ -1202,7 +1241,7 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
     double T[3];
     {
       double x[2][3], r[2][3];
-      load_t_sample(pts, pair, x, r);
+      load_t_sample(pts, m, pair, x, r);
       solve_T2<double>(x, r, pair[0] == pair[1], T);
     }
 #pragma unroll
@@ -1430,9 +1469,10 @@ __global__ void t_winner_kernel(const double* __restrict__ pts_all, CamOffsets o
   const long long i = (long long)(0xFFFFFFFFull - (key & 0xFFFFFFFFull));
   const long long h = (key == 0 || i >= nb) ? 0 : i;
   const double* pts = pts_all + 6 * offs.off[cam];
+  const int m = (int)(offs.off[cam + 1] - offs.off[cam]);
   const int32_t* pair = idx + 2 * ((long long)cam * nb + h);
   double x[2][3], r[2][3], T[3];
-  load_t_sample(pts, pair, x, r);
+  load_t_sample(pts, m, pair, x, r);
   solve_T2<double>(x, r, pair[0] == pair[1], T);
   if (threadIdx.x == 0) {
 #pragma unroll
@@ -1613,7 +1653,7 @@ const char* sfm_hip_error_string(int code) {
   return hipGetErrorString((hipError_t)code);
 }
 
-int sfm_hip_abi_version(void) { return 2; }
+int sfm_hip_abi_version(void) { return 3; }
 
 static int launch_eh_score(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, int32_t* count_e,
                            int32_t* count_h, hipStream_t st) {
@@ -1629,8 +1669,10 @@ static int launch_eh_score(const double* corr, int32_t n, const int32_t* idx, in
     e = hipMemsetAsync(count_h, 0, sizeof(int32_t) * nb, st);
     if (e != hipSuccess) return (int)e;
   }
-  eh_score_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, n, idx, nb, 2.0 * thr_e * thr_e, thr_h * thr_h,
-                                                                    count_e, count_h, pps, splits > 1);
+  // the reference squares the epipolar threshold (src/ransac_algorithm.py:102) but compares the transfer distance with
+  // 3 * threshold itself (:327): a non-positive thr_h admits nothing
+  eh_score_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, n, idx, nb, 2.0 * thr_e * thr_e,
+                                                                    thr_h > 0.0 ? thr_h * thr_h : -1.0, count_e, count_h, pps, splits > 1);
   return check_launch();
 }
 
@@ -1640,9 +1682,12 @@ int sfm_eh_score_f64(const double* corr, int32_t n, const int32_t* idx, int64_t 
   return launch_eh_score(corr, n, idx, nb, thr_e, thr_h, count_e, count_h, (hipStream_t)stream);
 }
 
+int64_t sfm_corr_f32_bytes(int32_t n) { return n < 0 ? -1 : ((int64_t)n + 1) * 16; }
+
 int sfm_corr_to_f32(const double* corr, int32_t n, float* corr32, void* stream) {
   clear_stale_error();
-  if (!corr || !corr32 || n < 0) return SFM_EINVAL;
+  if (!corr || !corr32 || n < 0 || ((uintptr_t)corr32 & 15u) != 0) return SFM_EINVAL;
+  SFM_TRY(hipMemsetAsync(corr32 + 4 * (size_t)n, 0, 16, (hipStream_t)stream));  // trailer: measured max |coordinate|
   if (n == 0) return 0;
   corr_to_f32_kernel<<<div_up(n, kBlock), kBlock, 0, (hipStream_t)stream>>>((const double4*)corr, n, (float4*)corr32);
   return check_launch();
@@ -1651,7 +1696,7 @@ int sfm_corr_to_f32(const double* corr, int32_t n, float* corr32, void* stream) 
 static int launch_eh_upper(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
                            double xmax, double safety, int32_t one_sided, int32_t* up_e, int32_t* up_h, hipStream_t st) {
   if (!corr || !corr32 || !idx || !up_e || !up_h || n <= 0 || nb < 0) return SFM_EINVAL;
-  if (!(xmax > 0.0 && xmax < 1.0e6 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
+  if (!(xmax >= 0.0 && xmax < 1.0e300 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
   if (nb == 0) return 0;
   const long long tiles = (nb + kBlock - 1) / kBlock;
   if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
@@ -1694,6 +1739,7 @@ int64_t sfm_corr_mfma_bytes(int32_t n) { return n <= 0 ? 0 : (int64_t)padded32(n
 static int launch_corr_to_mfma(const double* corr, int32_t n, double thr_e, void* corrm, hipStream_t st) {
   if (!corr || !corrm || n <= 0 || !(thr_e > 0.0) || ((uintptr_t)corrm & 15u) != 0) return SFM_EINVAL;
   const int npad = padded32(n);
+  SFM_TRY(hipMemsetAsync((char*)corrm + (size_t)npad * 40, 0, 16, st));  // trailer: threshold tag + measured max |coordinate|
   corr_to_mfma_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, 1.0 / sqrt(uniform_k1(2.0 * thr_e * thr_e)),
                                                                (uint4*)corrm, (float2*)((char*)corrm + (size_t)npad * 32));
   return check_launch();
@@ -1707,7 +1753,7 @@ int sfm_corr_to_mfma(const double* corr, int32_t n, double thr_e, void* corrm, v
 static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
                                 double xmax, double safety, int32_t* up_e, int32_t* up_h, hipStream_t st, int part = 0) {
   if (!corr || !corrm || !idx || !up_e || !up_h || n <= 0 || nb < 0 || ((uintptr_t)corrm & 15u) != 0) return SFM_EINVAL;
-  if (!(xmax > 0.0 && xmax < 1.0e6 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
+  if (!(xmax >= 0.0 && xmax < 1.0e300 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
   if (nb == 0) return 0;
   const long long tiles = (nb + kBlock - 1) / kBlock;
   if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
@@ -1753,17 +1799,17 @@ int sfm_eh_upper_mfma_part_f32(const double* corr, const void* corrm, int32_t n,
 
 int64_t sfm_eh_score_mixed_workspace_bytes(int64_t nb, int32_t n) {
   if (nb < 0 || n <= 0) return -1;
-  return ((int64_t)padded32(n) * 72 + 255) / 256 * 256;
+  return ((int64_t)padded32(n) * 72 + 16 + 255) / 256 * 256;
 }
 
-int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax, void* workspace,
-                       int64_t workspace_bytes, int32_t* count_e, int32_t* count_h, void* stream) {
-  clear_stale_error();
+// workspace: sfm_eh_score_mixed_workspace_bytes(nb, n) bytes of device memory, 256-byte aligned (checked by the callers)
+static int run_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax,
+                              void* workspace, int32_t* count_e, int32_t* count_h, hipStream_t st) {
   if (!corr || !idx || !count_e || !count_h || !workspace || n <= 0 || nb < 0) return SFM_EINVAL;
-  if (!(xmax > 0.0 && xmax < 1.0e6) || ((uintptr_t)workspace & 255u) != 0) return SFM_EINVAL;
-  if (workspace_bytes < sfm_eh_score_mixed_workspace_bytes(nb, n)) return SFM_EINVAL;
+  if (!(xmax >= 0.0 && xmax < 1.0e300)) return SFM_EINVAL;
   if (nb == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
+  // without positive thresholds there is no band to speak of: the float64 kernel answers (all counts zero for thr_h <= 0)
+  if (!(thr_e > 0.0 && thr_h > 0.0)) return launch_eh_score(corr, n, idx, nb, thr_e, thr_h, count_e, count_h, st);
   const long long tiles = (nb + kBlock - 1) / kBlock;
   if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
   const int npad = padded32(n);
@@ -1777,11 +1823,20 @@ int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_
     SFM_TRY(hipMemsetAsync(count_e, 0, sizeof(int32_t) * nb, st));
     SFM_TRY(hipMemsetAsync(count_h, 0, sizeof(int32_t) * nb, st));
   }
+  SFM_TRY(hipMemsetAsync(xy + npad, 0, 16, st));  // trailer: measured max |coordinate|
   corr_to_mfma2_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, pieces, xy);
   SFM_TRY(check_launch());
   eh_score_mfma_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e,
                                                                         thr_h * thr_h, xmax, count_e, count_h, tps, splits > 1);
   return check_launch();
+}
+
+int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax, void* workspace,
+                       int64_t workspace_bytes, int32_t* count_e, int32_t* count_h, void* stream) {
+  clear_stale_error();
+  if (!workspace || n <= 0 || nb < 0 || ((uintptr_t)workspace & 255u) != 0) return SFM_EINVAL;
+  if (workspace_bytes < sfm_eh_score_mixed_workspace_bytes(nb, n)) return SFM_EINVAL;
+  return run_eh_score_mixed(corr, n, idx, nb, thr_e, thr_h, xmax, workspace, count_e, count_h, (hipStream_t)stream);
 }
 
 // ---- the whole bound cascade as one call -------------------------------------------------
@@ -2016,7 +2071,7 @@ int sfm_eh_models_f64(const double* corr, int32_t n, const int32_t* idx, int64_t
   clear_stale_error();
   if (!corr || !idx || n <= 0 || nb < 0) return SFM_EINVAL;
   if (nb == 0) return 0;
-  eh_models_kernel<<<div_up(nb, kBlock), kBlock, 0, (hipStream_t)stream>>>((const double4*)corr, idx, nb, F_out, E_out, H_out);
+  eh_models_kernel<<<div_up(nb, kBlock), kBlock, 0, (hipStream_t)stream>>>((const double4*)corr, n, idx, nb, F_out, E_out, H_out);
   return check_launch();
 }
 
@@ -2032,7 +2087,7 @@ static int mask_common(bool epi, const double* M, const double* corr, int32_t n,
   if (epi)
     mask_kernel<true><<<div_up(n, kBlock), kBlock, 0, st>>>(M, (const double4*)corr, n, 2.0 * thr * thr, mask, count);
   else
-    mask_kernel<false><<<div_up(n, kBlock), kBlock, 0, st>>>(M, (const double4*)corr, n, thr * thr, mask, count);
+    mask_kernel<false><<<div_up(n, kBlock), kBlock, 0, st>>>(M, (const double4*)corr, n, thr > 0.0 ? thr * thr : -1.0, mask, count);
   return check_launch();
 }
 
@@ -2107,7 +2162,7 @@ int sfm_e_record_f64(const double* corr, int32_t n, const int32_t* row, double t
     r.v[i] = row[i];
   }
   SFM_TRY(hipMemsetAsync(scratch + kRecCnt, 0, 4 * sizeof(double), st));
-  models_from_row_kernel<<<1, 64, 0, st>>>((const double4*)corr, r, scratch + kRecE, scratch + kRecH);
+  models_from_row_kernel<<<1, 64, 0, st>>>((const double4*)corr, n, r, scratch + kRecE, scratch + kRecH);
   mask_kernel<true><<<div_up(n, kBlock), kBlock, 0, st>>>(scratch + kRecE, (const double4*)corr, n, 2.0 * thr * thr, mask,
                                                         (int32_t*)(scratch + kRecMaskCnt));
   essential_candidates_kernel<<<1, 64, 0, st>>>(scratch + kRecE, scratch + kRecP);
@@ -2129,7 +2184,7 @@ int sfm_h_record_f64(const double* corr, int32_t n, const int32_t* row, double t
   }
   SFM_TRY(hipMemsetAsync(scratch + kRecCnt, 0, 4 * sizeof(double), st));
   SFM_TRY(hipMemsetAsync(scratch + kRecCnt2, 0, 4 * sizeof(double), st));
-  models_from_row_kernel<<<1, 64, 0, st>>>((const double4*)corr, r, scratch + kRecE, scratch + kRecH);
+  models_from_row_kernel<<<1, 64, 0, st>>>((const double4*)corr, n, r, scratch + kRecE, scratch + kRecH);
   homography_to_rt_kernel<<<1, 1024, 0, st>>>(scratch + kRecH, (const double4*)corr, n, scratch + kRecRt);
   for (int k = 0; k < 2; ++k) {
     const double* E = scratch + kRecRt + (k ? 33 : 24);
@@ -2200,7 +2255,9 @@ int sfm_t_ransac_f64(const double* pts, const int64_t* cam_off, int32_t ncam, co
   }
   e = hipMemsetAsync(best, 0, sizeof(uint64_t) * ncam, st);
   if (e != hipSuccess) return (int)e;
-  t_score_kernel<<<dim3((unsigned)tiles, ncam, splits), kBlock, 0, st>>>(pts, offs, idx, nb, thr * thr, counts, pps, splits > 1);
+  // count_inliers compares a norm with the threshold itself (src/estimate_translation.py:127): a non-positive one admits nothing
+  t_score_kernel<<<dim3((unsigned)tiles, ncam, splits), kBlock, 0, st>>>(pts, offs, idx, nb, thr > 0.0 ? thr * thr : -1.0, counts, pps,
+                                                                         splits > 1);
   rc = check_launch();
   if (rc) return rc;
   const int ablocks = (int)(tiles < 256 ? tiles : 256);
@@ -2231,8 +2288,9 @@ int64_t sfm_t_ransac_mixed_workspace_bytes(const int64_t* cam_off, int32_t ncam)
 int sfm_t_ransac_mixed(const double* pts, const int64_t* cam_off, int32_t ncam, const int32_t* idx, int64_t nb, double thr, void* workspace,
                        int64_t workspace_bytes, int32_t* counts, uint64_t* best, double* T_best, void* stream) {
   clear_stale_error();
-  if (!pts || !idx || !counts || !best || !T_best || !workspace || nb <= 0 || !(thr > 0.0)) return SFM_EINVAL;
+  if (!pts || !idx || !counts || !best || !T_best || !workspace || nb <= 0) return SFM_EINVAL;
   if (((uintptr_t)workspace & 255u) != 0) return SFM_EINVAL;
+  if (!(thr > 0.0)) return sfm_t_ransac_f64(pts, cam_off, ncam, idx, nb, thr, counts, best, T_best, stream);  // nothing to band: all counts zero
   CamOffsets offs;
   int rc = fill_offsets(cam_off, ncam, &offs);
   if (rc) return rc;
@@ -2273,7 +2331,7 @@ int sfm_t_count_f64(const double* pts, int32_t m, const double* T, int64_t nb, d
   clear_stale_error();
   if (!pts || !T || !counts || m < 0 || nb < 0) return SFM_EINVAL;
   if (nb == 0) return 0;
-  t_count_kernel<<<div_up(nb, kBlock), kBlock, 0, (hipStream_t)stream>>>(pts, m, T, nb, thr * thr, counts);
+  t_count_kernel<<<div_up(nb, kBlock), kBlock, 0, (hipStream_t)stream>>>(pts, m, T, nb, thr > 0.0 ? thr * thr : -1.0, counts);
   return check_launch();
 }
 
@@ -2299,7 +2357,7 @@ int sfm_t_upper_f32(const double* pts, const float* pts32, const int64_t* cam_of
                     const double* rmax, double xmax, double safety, int32_t* up, void* stream) {
   clear_stale_error();
   if (!pts || !pts32 || !idx || !up || !rmax || nb <= 0) return SFM_EINVAL;
-  if (!(xmax > 0.0 && xmax < 1.0e6 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
+  if (!(xmax >= 0.0 && xmax < 1.0e300 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
   CamOffsets offs;
   int rc = fill_offsets(cam_off, ncam, &offs);
   if (rc) return rc;
@@ -2341,7 +2399,7 @@ int sfm_t_models_f64(const double* pts, int32_t m, const int32_t* idx, int64_t n
   clear_stale_error();
   if (!pts || !idx || !T_out || m <= 0 || nb < 0) return SFM_EINVAL;
   if (nb == 0) return 0;
-  t_models_kernel<<<div_up(nb, kBlock), kBlock, 0, (hipStream_t)stream>>>(pts, idx, nb, T_out);
+  t_models_kernel<<<div_up(nb, kBlock), kBlock, 0, (hipStream_t)stream>>>(pts, m, idx, nb, T_out);
   return check_launch();
 }
 

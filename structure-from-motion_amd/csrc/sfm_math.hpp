@@ -88,8 +88,9 @@ SFM_FN void null_vector_9x8(T (&a)[9][8], T (&q)[9]) {
 // On return the columns of g are sigma_i * u_i (mutually orthogonal) and v holds the right
 // singular vectors as columns, A v_i = g_i.  Relative accuracy ~eps even for the smallest
 // singular vector, which is what DLT triangulation needs (src/utils.py:30-31).
-// The sweep loop exits when every lane of the wave has converged; callers keep all 64 lanes
-// active.
+// The sweep loop exits when every lane of the wave has converged (callers keep all 64 lanes
+// active), but a lane stops rotating with its OWN first converged sweep: the result depends on
+// the lane's matrix only, never on which other models share the wave.
 // ---------------------------------------------------------------------------------------
 template <typename T, int N>
 SFM_FN void jacobi_svd(T (&g)[N][N], T (&v)[N][N]) {
@@ -98,6 +99,7 @@ SFM_FN void jacobi_svd(T (&g)[N][N], T (&v)[N][N]) {
 #pragma unroll
     for (int j = 0; j < N; ++j) v[i][j] = (i == j) ? T(1) : T(0);
   const T tol = T(4) * num_traits<T>::eps;
+  bool done = false;
   for (int sweep = 0; sweep < 16; ++sweep) {
     T off = T(0);
 #pragma unroll
@@ -113,7 +115,7 @@ SFM_FN void jacobi_svd(T (&g)[N][N], T (&v)[N][N]) {
         }
         const T lim = tsqrt(al * be);
         const T aga = tabs(ga);
-        const bool rot = aga > num_traits<T>::eps * lim;
+        const bool rot = !done && aga > num_traits<T>::eps * lim;
         if (rot) off = fmax(off, aga / lim);
         const T zeta = (be - al) / (T(2) * ga);
         T t = copysign(T(1), zeta) / (tabs(zeta) + tsqrt(fma(zeta, zeta, T(1))));
@@ -131,7 +133,8 @@ SFM_FN void jacobi_svd(T (&g)[N][N], T (&v)[N][N]) {
         }
       }
     }
-    if (SFM_WAVE_ALL(off <= tol)) break;
+    done = done || off <= tol;
+    if (SFM_WAVE_ALL(done)) break;
   }
 }
 

@@ -52,9 +52,10 @@ def eh_score(corr, idx, thr_e, thr_h, out=None):
     return ce, ch
 
 
-def eh_score_mixed(corr, idx, thr_e, thr_h, xmax, out=None, workspace=None):
+def eh_score_mixed(corr, idx, thr_e, thr_h, xmax=0.0, out=None, workspace=None):
     """The counts of eh_score (identical for every hypothesis) with the residual tests on the matrix cores + float32 and a
-    float64 re-evaluation of the pairs inside the error band.  xmax: max |coordinate| over corr (host float)."""
+    float64 re-evaluation of the pairs inside the error band.  xmax: optional hint of max |coordinate| over corr; the
+    library measures it on the device and uses the larger value."""
     torch = C.torch_cuda()
     lib = C.load_library()
     nb, n = idx.shape[0], corr.shape[0]
@@ -71,16 +72,18 @@ def eh_score_mixed(corr, idx, thr_e, thr_h, xmax, out=None, workspace=None):
 
 
 def corr_to_f32(corr):
+    """float32 copy [n + 1][4] of the matches: row n is a trailer whose first word is the measured max |coordinate|."""
     torch = C.torch_cuda()
     lib = C.load_library()
-    out = _empty((corr.shape[0], 4), torch.float32)
+    out = _empty((int(lib.sfm_corr_f32_bytes(corr.shape[0])) // 16, 4), torch.float32)
     C.check(lib.sfm_corr_to_f32(C.dptr(corr), corr.shape[0], C.dptr(out), C.stream_ptr()))
     return out
 
 
 def eh_upper(corr, corr32, idx, thr_e, thr_h, xmax, safety=2.0, out=None, one_sided=False):
     """float32 pre-filter: upper bounds (up_e, up_h) int32 [B] of the exact counts.
-    xmax: max |coordinate| over corr (host float).  one_sided: cheaper, looser bound for E."""
+    xmax: hint of max |coordinate| over corr (0 = unknown; the measured value in corr32 is used when larger).
+    one_sided: cheaper, looser bound for E."""
     torch = C.torch_cuda()
     lib = C.load_library()
     nb = idx.shape[0]

@@ -150,16 +150,13 @@ class GpuBackend:
         corr_h = ops.pack_corr(x1, x2)
         self.corr = C.dev(corr_h)
         self.n = self.corr.shape[0]
-        self.xmax = float(np.abs(corr_h).max()) if corr_h.size else 0.0
         self.scratch = ops.RecordScratch(self.n)
 
     def score(self, idx):
         d_idx = C.dev(idx, np.int32)
-        if 0.0 < self.xmax < 1.0e6:
-            # identical counts, residual tests on the matrix cores + float32 with float64 inside the error band
-            ce, ch = ops.eh_score_mixed(self.corr, d_idx, self.thr, 3 * self.thr, self.xmax)
-        else:
-            ce, ch = ops.eh_score(self.corr, d_idx, self.thr, 3 * self.thr)
+        # float64 counts; the residual tests run on the matrix cores + float32 with float64 inside the error band
+        # (the library measures the coordinate range itself and evaluates everything in float64 when it is unusable)
+        ce, ch = ops.eh_score_mixed(self.corr, d_idx, self.thr, 3 * self.thr)
         return ce.cpu().numpy(), ch.cpu().numpy()
 
     def e_record(self, row):

@@ -49,7 +49,7 @@ int main() {
   float* d_corr32;
   int32_t *d_idx, *d_ce, *d_ch;
   CHECK(hipMalloc(&d_corr, corr.size() * sizeof(double)));
-  CHECK(hipMalloc(&d_corr32, 4 * (size_t)n * sizeof(float)));
+  CHECK(hipMalloc(&d_corr32, (size_t)sfm_corr_f32_bytes(n)));
   CHECK(hipMalloc(&d_idx, 12 * nb * sizeof(int32_t)));
   CHECK(hipMalloc(&d_ce, nb * sizeof(int32_t)));
   CHECK(hipMalloc(&d_ch, nb * sizeof(int32_t)));
