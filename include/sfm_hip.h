@@ -40,6 +40,7 @@ extern "C" {
 #endif
 
 #define SFM_EINVAL 100001
+#define SFM_ETOOLARGE 100002 /* sfm_eh_score_noalloc: n > SFM_NOALLOC_MAX_MATCHES */
 
 const char* sfm_hip_error_string(int code);
 int sfm_hip_abi_version(void);
@@ -112,6 +113,16 @@ int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_
 int64_t sfm_eh_score_mixed_workspace_bytes(int64_t nb, int32_t n);
 int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax,
                        void* workspace, int64_t workspace_bytes, int32_t* count_e, int32_t* count_h, void* stream);
+
+/* sfm_eh_score_mixed for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): same counts, no workspace argument, and no hipMalloc / hipFree or other
+ * allocating call inside.  It has no counterpart in the reference.  The match-side operands (72 bytes per match) go into
+ * a fixed array inside the library, SFM_NOALLOC_MAX_MATCHES * 72 bytes (2.25 MiB) that every GPU the library runs on
+ * holds until the process ends; n beyond that capacity is rejected with SFM_ETOOLARGE.  All calls on one GPU share
+ * that array: calls that overlap on one GPU (different streams or threads) race; calls on one stream are safe. */
+#define SFM_NOALLOC_MAX_MATCHES 32768
+int sfm_eh_score_noalloc(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
+                         int32_t* count_e, int32_t* count_h, void* stream);
 
 /* The models themselves: F_out (estimate_F_DLT, :216-263, before the singular values are
  * replaced), E_out (after enforce_essential, :176-190) and H_out (estimate_H_DLT, :266-293),

@@ -13,6 +13,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "../../include/sfm_hip.h"
 #include "sfm_math.hpp"
 
@@ -1650,6 +1652,7 @@ extern "C" {
 
 const char* sfm_hip_error_string(int code) {
   if (code == SFM_EINVAL) return "sfm_hip: invalid argument";
+  if (code == SFM_ETOOLARGE) return "sfm_hip: more matches than the fixed scratch of the no-allocation entry point holds (SFM_NOALLOC_MAX_MATCHES)";
   return hipGetErrorString((hipError_t)code);
 }
 
@@ -1837,6 +1840,45 @@ int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_
   if (!workspace || n <= 0 || nb < 0 || ((uintptr_t)workspace & 255u) != 0) return SFM_EINVAL;
   if (workspace_bytes < sfm_eh_score_mixed_workspace_bytes(nb, n)) return SFM_EINVAL;
   return run_eh_score_mixed(corr, n, idx, nb, thr_e, thr_h, xmax, workspace, count_e, count_h, (hipStream_t)stream);
+}
+
+// ---- the same scoring for callers that cannot allocate ---------------------------------------
+// The match-side operands live in a file-scope device array instead of a caller workspace.  Each GPU holds its own
+// copy of the array at its own address: the address is looked up once per device (with that device current) and kept;
+// host code only ever uses that looked-up pointer, never the array's name.
+static constexpr size_t kNoallocBytes = ((size_t)SFM_NOALLOC_MAX_MATCHES * 72 + 16 + 255) / 256 * 256;
+static __device__ __align__(256) unsigned char scratch[kNoallocBytes];
+namespace {
+constexpr int kMaxDevices = 64;
+void* g_noalloc_ptr[kMaxDevices] = {};
+std::mutex g_noalloc_mutex;
+
+int noalloc_scratch(void** out) {
+  int dev = -1;
+  SFM_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return SFM_EINVAL;
+  std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+  if (!g_noalloc_ptr[dev]) {
+    void* p = nullptr;
+    SFM_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return SFM_EINVAL;
+    g_noalloc_ptr[dev] = p;
+  }
+  *out = g_noalloc_ptr[dev];
+  return 0;
+}
+}  // namespace
+
+int sfm_eh_score_noalloc(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, int32_t* count_e,
+                         int32_t* count_h, void* stream) {
+  clear_stale_error();
+  if (n <= 0 || nb < 0) return SFM_EINVAL;
+  if (n > SFM_NOALLOC_MAX_MATCHES) return SFM_ETOOLARGE;
+  void* ws = nullptr;
+  SFM_TRY(noalloc_scratch(&ws));
+  // run_eh_score_mixed rewrites every operand of the n (padded to 32) matches and zeroes the 16-byte trailer that the
+  // measurement of max |coordinate| accumulates into, so nothing of an earlier call is read
+  return run_eh_score_mixed(corr, n, idx, nb, thr_e, thr_h, 0.0, ws, count_e, count_h, (hipStream_t)stream);
 }
 
 // ---- the whole bound cascade as one call -------------------------------------------------
