@@ -21,7 +21,7 @@ def main(d):
             rows = c.execute("select name, start, end from kernels order by start").fetchall()
             per = {}
             for name, st, en in rows:
-                if "eh_upper" in name or ("eh_score" in name) or "t_score" in name or "knn2_kernel" in name:
+                if "eh_upper" in name or ("eh_score" in name) or "t_score" in name or "knn2_kernel" in name or "eh_solve" in name:
                     per.setdefault(name[:80], []).append((en - st) / 1e3)
             for name, durs in per.items():
                 big = [x for x in durs if x > 0.25 * max(durs)]
@@ -44,7 +44,7 @@ def main(d):
             "max(duration) dur from pmc_events group by name, counter_name, dispatch_id) group by name, counter_name"
         ).fetchall()
         for name, cn, v, n, dur in rows:
-            if "eh_upper" in name or "eh_score" in name or "t_score" in name or "argmax" in name or "lm_kernel" in name or "knn2" in name:
+            if "eh_upper" in name or "eh_score" in name or "eh_solve" in name or "t_score" in name or "argmax" in name or "lm_kernel" in name or "knn2" in name:
                 print(f"{name[:70]:70s} | {cn:22s} | {v:18.1f} | dispatches {n} | avg dur {dur/1e3:10.1f} us")
 
 

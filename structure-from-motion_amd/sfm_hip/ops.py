@@ -108,7 +108,7 @@ def corr_to_mfma(corr, thr_e):
     return corrm
 
 
-def eh_upper_mfma(corr, corrm, idx, thr_e, thr_h, xmax, safety=2.0, out=None, part=0):
+def eh_upper_mfma(corr, corrm, idx, thr_e, thr_h, xmax=0.0, safety=2.0, out=None, part=0):
     """Loose float32 upper bounds like eh_upper(one_sided=True), with E x1 and H x1 on the bf16 matrix cores.
     part=1 / 2 (measurement aid): only the epipolar / only the transfer test."""
     torch = C.torch_cuda()
