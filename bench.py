@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """Benchmark of the robust-estimation hot path on MI355X.
 
-Workload (N=1): the synthetic two-view E+H RANSAC configuration: 10 000 SIFT-like matches,
-30 % inliers, 10^6 hypotheses per GPU.  One step = one pass of the fused solver + scoring
-kernel over all hypotheses of this rank (every hypothesis: 8-point E and 4-point H model,
-both scored against all matches) plus the arg-max of the inlier counts and, for N>1, the
-merge of the per-rank winners by one all-reduce(max) of packed (count, index) keys.
+Workload, one GPU (--workload c2, the default for N=1): the synthetic two-view E+H RANSAC configuration: 10 000
+SIFT-like matches, 30 % inliers, 10^6 hypotheses.  One step = one pass of the fused solver + scoring kernel over
+all hypotheses (every hypothesis: 8-point E and 4-point H model, both scored against all matches) plus the arg-max
+of the inlier counts.
+
+Workload, several GPUs (--workload c5, the default for N>1; also runs on one GPU): 200 000 matches x 10^8
+hypotheses, STRONG scaling: the hypothesis ids [0, 10^8) are split into contiguous ranges, one per rank
+(sfm_hip.sharding.shard_range); every rank generates the index sets of its ids on its own GPU (Philox keyed by
+(seed, id): identical under any split), finds the exact winners of its range and the ranks merge them with one
+all-reduce(max) of packed (count, index) keys per step.  A step is one pass over all 10^8 hypotheses.
 
 Metric: hypothesis x correspondence residual evaluations per second (an E residual and an H
 residual each count as one evaluation).  Inputs (matches and index sets) are resident in HBM
@@ -30,9 +35,61 @@ import numpy as np  # noqa: E402
 
 FLOPS_PER_E_EVAL = 36  # algorithmic cost of one symmetric-epipolar residual test
 FLOPS_PER_H_EVAL = 21  # one transfer-error residual test
+FLOPS_PER_T_EVAL = 12  # one reprojection residual test (R X precomputed)
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32
 PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector FP64 (half of the FP32 vector rate)
-PMC_TRAFFIC_BYTES = (2 * 26441.5 + 7812.5) * 1024  # FETCH_SIZE x2 + WRITE_SIZE of the dominant kernel, KB -> bytes
+SPEC_CLOCK_HZ = 2.4e9
+N_SIMD = 1024  # 256 CUs x 4
+# a pure v_fma_f32 stream on this chip under sustained load (kernels of 10+ ms, 4 waves per SIMD):
+# profiles/microbench/mfma_valu_overlap_mi355x.txt, row "M=0 MFMA N= 96 VALU waves/SIMD 4"
+SUSTAINED_NS_PER_VALU_INSTRUCTION = 19.903e6 / (4 * 40000 * 96)
+
+
+def load_profile_counters(matches, hyps):
+    """Per-launch counters of the newest profiles/*_counters.json (written by profiles/summarize.py from separate
+    rocprofv3 --pmc passes of this same command on the default workload).  Instruction counts and HBM traffic per
+    launch are properties of kernel + workload, so they combine with the durations measured live here."""
+    import glob
+
+    if (matches, hyps) != (10000, 1000000):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return json.load(f), os.path.relpath(files[-1], ROOT)
+
+
+def kernel_counters(table, needle):
+    if not table:
+        return {}
+    for name, c in table.items():
+        if needle in name and "SQ_INSTS_VALU" in c:
+            return c
+    return {}
+
+
+def issue_roofline(kernel_ms, c):
+    """Counter-derived utilisation of the vector issue slots: every VALU wave-instruction occupies a SIMD for 2 cycles
+    (64 lanes over a 32-lane SIMD), every bf16 32x32x16 MFMA occupies the matrix pipe for 32."""
+    if not c or "SQ_INSTS_VALU" not in c:
+        return None
+    t = kernel_ms * 1e-3
+    out = {
+        "valu_instructions_per_launch": c["SQ_INSTS_VALU"],
+        "valu_issue_frac_at_spec_clock": c["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * SPEC_CLOCK_HZ * t),
+        "fma_equivalent_tflops": c["SQ_INSTS_VALU"] * 128.0 / t / 1e12,
+        "valu_issue_frac_of_sustained_fma_stream": c["SQ_INSTS_VALU"] * SUSTAINED_NS_PER_VALU_INSTRUCTION * 1e-9 / (N_SIMD * t),
+    }
+    if "SQ_INSTS_MFMA" in c:
+        out["mfma_instructions_per_launch"] = c["SQ_INSTS_MFMA"]
+        out["mfma_pipe_busy_frac_at_spec_clock"] = c["SQ_INSTS_MFMA"] * 32.0 / (N_SIMD * SPEC_CLOCK_HZ * t)
+    if "GRBM_GUI_ACTIVE" in c and c.get("GRBM_GUI_ACTIVE__dur_us"):
+        out["clock_ghz_under_the_profiler"] = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["GRBM_GUI_ACTIVE__dur_us"] * 1e-6) / 1e9
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # gfx950 tallies 128-byte read requests as 64 bytes: FETCH_SIZE is doubled; both counters are in KB
+        out["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    return out
 
 
 def cpu_baseline(x1n, x2n, thr, n_matches, idx):
@@ -104,7 +161,7 @@ def cpu_baseline_all_cores(n, seed, workers, hyps_per_worker):
             f"(slowest worker {max(busy):.1f} s, pool start {t1 - t0:.1f} s not counted)"}
 
 
-def secondary_measurements(torch, ops, _capi, synthetic, seed):
+def secondary_measurements(torch, ops, _capi, synthetic, seed, table=None):
     """Timings of the other rows of the path (not part of `value`): the batched 2-point
     translation RANSAC (12 cameras x 50 000 correspondences x 100 000 hypotheses) and the
     batched LM refinement + DLT triangulation over 12 cameras of dataset-10-like sizes."""
@@ -159,6 +216,19 @@ def secondary_measurements(torch, ops, _capi, synthetic, seed):
         "two_tier_tflops_algorithmic_12_per_eval": 12.0 * ncam * m * B / (ms2 * 1e-3) / 1e12,
         "two_tier_equals_f64": bool((c2 == cnt).all() and (i2 == ind).all() and (T2 == T.cpu().numpy()).all()),
         "best_counts": [int(c) for c in cnt],
+        "roofline": {
+            "bound": "valu_fp32",
+            "kernel": "t_score_mfma_kernel (dx, dy and thr*pz on the bf16 matrix cores, float32 sign test, float64 inside the error band; "
+            "evaluates the reference's reprojection test for every pair); kernel_ms is the whole call (operand preparation, arg-max and winner "
+            "kernels included: microseconds)",
+            "kernel_ms": ms_mixed,
+            "achieved": FLOPS_PER_T_EVAL * ncam * float(m) * B / (ms_mixed * 1e-3) / 1e12,
+            "peak": PEAK_FP32_VALU_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": FLOPS_PER_T_EVAL * ncam * float(m) * B / (ms_mixed * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+            "flops_per_eval": FLOPS_PER_T_EVAL,
+            "issue": issue_roofline(ms_mixed, kernel_counters(table, "t_score_mfma_kernel")),
+        },
     }
     # C4-like: LM (10 iterations, mu = 0.01) and triangulation with per-camera sizes 1e2..1e4
     sizes = [100, 300, 1000, 3000, 10000, 5000, 2000, 800, 400, 200, 6000, 1500]
@@ -311,13 +381,120 @@ def e2e(torch, synthetic, orc, seed, with_cpu):
     return out
 
 
+C5_MATCHES, C5_HYPOTHESES, C5_BLOCK = 200000, 100000000, 12500000
+
+
+def run_c5(args, torch, dist, orc, _capi, ops, sharding, synthetic, world, rank, key_device):
+    """200 000 matches x 10^8 hypotheses, strong scaling over the ranks (see the module docstring)."""
+    n, total = args.matches or C5_MATCHES, args.hyps or C5_HYPOTHESES
+    sc = synthetic.two_view_scene(n=n, inlier_ratio=0.3, planar_ratio=0.5, seed=args.seed)
+    thr = 1.0 / sc["K"][0][0]
+    x1n = orc.normalize_K(sc["K"], sc["x1"])
+    x2n = orc.normalize_K(sc["K"], sc["x2"])
+    corr = _capi.dev(ops.pack_corr(x1n, x2n))
+    corr32 = ops.corr_to_f32(corr)
+    lo, hi = sharding.shard_range(total, rank, world)
+    # this rank's ids in blocks of at most C5_BLOCK hypotheses; the index sets are generated here, on this GPU, and stay
+    # resident (48 bytes per hypothesis: 4.8 GB for all 10^8 on one GPU)
+    blocks = [(a, min(hi, a + C5_BLOCK)) for a in range(lo, hi, C5_BLOCK)]
+    idx = [ops.index_sets(args.seed, a, b - a, n) for a, b in blocks]
+    depth = 1 if args.no_overlap else 2
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    bmax = max(b - a for a, b in blocks)
+    workspaces = [ops.eh_best_workspace(bmax, n) for _ in range(depth)]
+    pendings = [ops.eh_best_pending() for _ in range(depth)]
+    best = torch.zeros(2, dtype=torch.int64, device=key_device)
+    stats = {"candidates_e": 0, "candidates_h": 0, "tightened": 0, "rescored_f64": 0}
+    torch.cuda.synchronize()
+
+    def step():
+        keys = [0, 0]
+        jobs = []
+
+        def finish(job, base):
+            (cE, iE), (cH, iH), st = ops.eh_best_collect(job)
+            for k in stats:
+                stats[k] += st[k]
+            keys[0] = max(keys[0], sharding.pack_key(cE, base + iE))
+            keys[1] = max(keys[1], sharding.pack_key(cH, base + iH))
+
+        for i, (a, b) in enumerate(blocks):
+            job = ops.eh_best_submit(corr, corr32, idx[i], thr, 3 * thr, 0.0, workspace=workspaces[i % depth], stream=streams[i % depth],
+                                     pending=pendings[i % depth])
+            jobs.append((job, a))
+            if len(jobs) == depth:
+                finish(*jobs.pop(0))
+        while jobs:
+            finish(*jobs.pop(0))
+        best.copy_(torch.tensor(keys, dtype=torch.int64))
+        sharding.merge_best(best)  # RCCL all-reduce(max) of the packed winners
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    for k in stats:
+        stats[k] = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=key_device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank != 0:
+        return
+    cnt, ind = ops.decode_best(best.cpu().numpy())
+    out = {
+        "metric": "RANSAC hyp x corr residual evals/sec",
+        "value": 2.0 * n * total * args.steps / dt,
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32+f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"synthetic two-view E+H RANSAC: {n} matches, 30% inliers, {total} hypotheses in total split into contiguous id ranges over "
+            f"{world} GPU(s) (8-pt E + 4-pt H solved per hypothesis; residual evaluations counted as bounded pairs: every (hypothesis, match) pair "
+            "takes the matrix-core bound tests, candidates are re-scored in float64; exact winner = first maximum of the float64 inlier counts), "
+            "winners merged by one all-reduce(max) of packed keys per step",
+            "matches": n,
+            "hypotheses_total": total,
+            "hypotheses_this_rank": hi - lo,
+            "blocks_per_rank": len(blocks),
+            "index_sets": "Philox4x32-10 on the device, keyed by (seed, global hypothesis id)",
+            "pixel_threshold": 1.0,
+            "winner_E": {"count": int(cnt[0]), "index": int(ind[0])},
+            "winner_H": {"count": int(cnt[1]), "index": int(ind[1])},
+            "f64_rescored_candidates_per_step": {k: v / args.steps for k, v in stats.items()},
+        },
+        "roofline": {"note": "the dominant kernel and its counters are those of the one-GPU default run (`python bench.py`); this line is the "
+                     "scaling measurement"},
+    }
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--matches", type=int, default=10000)
-    ap.add_argument("--hyps", type=int, default=1000000, help="hypotheses per GPU")
+    ap.add_argument("--workload", choices=["auto", "c2", "c5"], default="auto",
+                    help="c2: 10 000 matches x 10^6 hypotheses per GPU (weak scaling); c5: 200 000 matches x 10^8 hypotheses in total, split over "
+                    "the GPUs (strong scaling); auto = c2 on one GPU, c5 on several")
+    ap.add_argument("--matches", type=int, default=0, help="0 = the workload's own size")
+    ap.add_argument("--hyps", type=int, default=0, help="c2: hypotheses per GPU; c5: hypotheses in total; 0 = the workload's own size")
     ap.add_argument("--cpu-sample", type=int, default=50000, help="hypotheses of the CPU baseline sample (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--index-source", choices=["auto", "legacy", "philox"], default="auto",
@@ -327,18 +504,28 @@ def main():
                     help="torch.distributed backend for N>1: nccl (= RCCL over xGMI, one GPU per rank); gloo only to rehearse the "
                     "multi-rank path on a box with fewer GPUs than ranks (ranks then share GPUs)")
     ap.add_argument("--no-overlap", action="store_true", help="one step at a time on one stream (no overlap of a step's tail with the next step)")
-    ap.add_argument("--cpu-all-cores", type=int, default=0, metavar="WORKERS",
-                    help="also time the NumPy oracle on WORKERS host processes (hypothesis-range sharding) before the GPU is touched")
+    ap.add_argument("--cpu-all-cores", type=int, default=-1, metavar="WORKERS",
+                    help="also time the NumPy oracle on WORKERS host processes (hypothesis-range sharding) before the GPU is touched; "
+                    "-1 = this job's share of the host cores (OMP_NUM_THREADS when set, else os.cpu_count()), 0 = skip")
     ap.add_argument("--no-secondary", action="store_true", help="skip the T-RANSAC / LM / triangulation timings")
     ap.add_argument("--e2e", action="store_true", help="only run the synthetic dataset-5-shaped end-to-end geometry and print it")
     ap.add_argument("--e2e-cpu", action="store_true", help="with --e2e: also time the NumPy oracle end to end (minutes) and compare")
     ap.add_argument("--sweep", action="store_true", help="only run the match-count sweep (2k..200k matches) and print it")
     args = ap.parse_args()
 
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    workload = args.workload if args.workload != "auto" else ("c2" if world_env == 1 else "c5")
     all_cores = None
-    if args.cpu_all_cores > 0 and int(os.environ.get("RANK", "0")) == 0:
+    side_runs = args.e2e or args.sweep
+    if args.cpu_all_cores < 0:
+        try:
+            share = int(os.environ.get("OMP_NUM_THREADS", "0"))
+        except ValueError:
+            share = 0
+        args.cpu_all_cores = min(os.cpu_count() or 1, share) if share > 0 else (os.cpu_count() or 1)
+    if workload == "c2" and world_env == 1 and not side_runs and args.cpu_sample > 0 and args.cpu_all_cores > 0:
         # worker processes are started before this process initialises the GPU
-        all_cores = cpu_baseline_all_cores(args.matches, args.seed, args.cpu_all_cores, 20000)
+        all_cores = cpu_baseline_all_cores(args.matches or 10000, args.seed, args.cpu_all_cores, 20000)
 
     import torch
     import torch.distributed as dist
@@ -370,8 +557,14 @@ def main():
         print(json.dumps({"sweep": sweep(torch, ops, _capi, synthetic, orc, args.seed)}))
         return
 
+    if workload == "c5":
+        run_c5(args, torch, dist, orc, _capi, ops, sharding, synthetic, world, rank, key_device)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     # ---- workload: every rank holds the same matches and its own hypothesis range -----------
-    n, B = args.matches, args.hyps
+    n, B = args.matches or 10000, args.hyps or 1000000
     sc = synthetic.two_view_scene(n=n, inlier_ratio=0.3, planar_ratio=0.5, seed=args.seed)
     thr = 1.0 / sc["K"][0][0]
     x1n = orc.normalize_K(sc["K"], sc["x1"])
@@ -437,6 +630,20 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # the same steps strictly one after the other on one stream (no overlap of a step's tail with the next step)
+    no_overlap_ms = None
+    if depth > 1 and world == 1:
+        def run_serial(k):
+            for _ in range(k):
+                finish(ops.eh_best_submit(corr, corr32, idx, thr, 3 * thr, xmax, workspace=workspaces[0], stream=streams[0], pending=pendings[0]))
+
+        run_serial(2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_serial(args.steps)
+        torch.cuda.synchronize()
+        no_overlap_ms = (time.perf_counter() - t1) / args.steps * 1e3
+
     # ---- kernel time of the dominant kernel, HIP events on the launch stream -----------------
     corrm = ops.corr_to_mfma(corr, thr)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -501,6 +708,56 @@ def main():
         flops_per_launch = float(B) * n * (FLOPS_PER_E_EVAL + FLOPS_PER_H_EVAL)
         achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
         cnt, ind = ops.decode_best(best.cpu().numpy())
+        table, counters_file = load_profile_counters(n, B)
+        dom = issue_roofline(kern_ms, kernel_counters(table, "eh_upper_mfma_kernel"))
+        exact = issue_roofline(mixed_ms, kernel_counters(table, "eh_score_mfma_kernel"))
+        # Headline fraction: share of the chip's vector issue slots (at the 2.4 GHz spec clock) that the dominant kernel fills,
+        # from its measured instruction count per launch and its duration measured here.  It cannot exceed 1.
+        roofline = {
+            "bound": "valu_fp32",
+            "kernel": "eh_upper_mfma_kernel (float32 bounds: one-sided epipolar + box transfer test; E x1 and H x1 on the bf16 "
+            "matrix cores from three-piece splits, the rest on the vector ALU; float64 model solve included)",
+            "achieved": dom["fma_equivalent_tflops"] if dom else None,
+            "peak": PEAK_FP32_VALU_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": dom["valu_issue_frac_at_spec_clock"] if dom else None,
+            "traffic": dom.get("hbm_bytes_per_launch") if dom else None,
+            "traffic_unit": "bytes per launch: FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes of this command (the file named in "
+            "counters_from); algorithmic bytes are 48 MB of index sets + 0.3 MB of matches read, 8 MB of counts written",
+            "counters_from": counters_file,
+            "kernel_ms": kern_ms,
+            "definition": "achieved = vector instructions issued per launch (SQ_INSTS_VALU) x 64 lanes x 2 flops / kernel time, i.e. the flops "
+            "the occupied issue slots would deliver as FMAs; frac = achieved / peak = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x "
+            "kernel time)",
+            "issue": dom,
+            "sustained_reference": {
+                "ns_per_valu_instruction_per_simd": SUSTAINED_NS_PER_VALU_INSTRUCTION,
+                "note": "a pure independent v_fma_f32 stream, 4 waves per SIMD, kernels of 20 ms, holds this rate on the same chip (the clock "
+                "settles near 1.5 GHz under sustained vector load: profiles/microbench/mfma_valu_overlap_mi355x.txt); "
+                "issue.valu_issue_frac_of_sustained_fma_stream prices the kernel against it",
+            },
+            "algorithmic": {
+                "flops_per_launch": flops_per_launch,
+                "tflops": achieved,
+                "note": "secondary: 36 flops per epipolar + 21 per transfer residual of the reference's formulas per (hypothesis, match) pair. "
+                "The dominant kernel does NOT evaluate those formulas: it evaluates cheaper implied tests (12 vector instructions + 6/1024 "
+                "matrix instructions per pair) whose counts bound the exact ones, so this figure is a rate of bounded pairs, not a roofline "
+                "fraction; the exact formulas are priced under exact_mixed_kernel and f64_kernel",
+            },
+            "per_test": {"epipolar_only_kernel_ms": part_ms["epipolar"], "epipolar_evals_per_s": float(B) * n / (part_ms["epipolar"] * 1e-3),
+                         "transfer_only_kernel_ms": part_ms["transfer"], "transfer_evals_per_s": float(B) * n / (part_ms["transfer"] * 1e-3),
+                         "note": "each launch still solves both models"},
+            "exact_mixed_kernel": {"kernel": "eh_score_mfma_kernel (what estimate_E_robust runs: the float64 counts of every hypothesis from matrix "
+                                   "cores + float32, float64 inside the error bands; evaluates the reference's tests for every pair)",
+                                   "kernel_ms": mixed_ms, "achieved": flops_per_launch / (mixed_ms * 1e-3) / 1e12, "peak": PEAK_FP32_VALU_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": flops_per_launch / (mixed_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                                   "counts_identical_to_f64_kernel": mixed_identical, "issue": exact},
+            "f64_kernel": {"kernel": "eh_score_kernel (every test in float64)", "kernel_ms": f64_ms,
+                           "achieved": flops_per_launch / (f64_ms * 1e-3) / 1e12, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                           "frac": flops_per_launch / (f64_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS},
+            "loose_valu_kernel": {"kernel": "eh_upper_kernel<true>", "kernel_ms": loose_valu_ms},
+            "tight_f32_kernel": {"kernel": "eh_upper_kernel<false>", "kernel_ms": tight_ms},
+        }
         out = {
             "metric": "RANSAC hyp x corr residual evals/sec",
             "value": evals_per_step * args.steps / dt,
@@ -516,7 +773,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"synthetic two-view E+H RANSAC: {n} matches, 30% inliers, {B} hypotheses per GPU "
-                "(8-pt E + 4-pt H solved and scored per hypothesis; exact winner = first maximum of the inlier counts), "
+                "(8-pt E + 4-pt H solved per hypothesis; residual evaluations counted as bounded pairs: every (hypothesis, match) pair takes the "
+                "matrix-core bound tests, candidates are re-scored in float64; exact winner = first maximum of the float64 inlier counts), "
                 "winners merged by all-reduce(max)",
                 "matches": n,
                 "hypotheses_per_gpu": B,
@@ -527,52 +785,11 @@ def main():
                 "winner_H": {"count": int(cnt[1]), "index": int(ind[1])},
                 "f64_rescored_candidates": dict(last_stats),
             },
-            "roofline": {
-                "bound": "valu_fp32",
-                "kernel": "eh_upper_mfma_kernel (float32 bounds: one-sided epipolar + box transfer test; E x1 and H x1 on the bf16 "
-                "matrix cores from three-piece splits, the rest on the vector ALU)",
-                "achieved": achieved,
-                "peak": PEAK_FP32_VALU_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                # HBM bytes per launch from rocprofv3 PMC passes of this same command (the latest summary under profiles/):
-                # FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE; algorithmic bytes are
-                # 48 MB of index sets + 0.5 MB of matches read, 8 MB of counts written.
-                "traffic": PMC_TRAFFIC_BYTES if (n, B) == (10000, 1000000) else None,
-                "traffic_unit": "bytes per launch (PMC, measured in a separate rocprofv3 run)",
-                "kernel_ms": kern_ms,
-                "flops_per_launch": flops_per_launch,
-                "note": "not HBM-bound: each match is reused by every hypothesis of a workgroup. `achieved` uses the "
-                "algorithmic cost of the reference's tests (36 flops per E residual + 21 per H residual) and is priced against "
-                "the float32 vector peak, which bounds the part that is not GEMM shaped; the kernel reaches the exact winner with "
-                "cheaper implied tests, moves the two 3x3 products (24 of its 43 flops per pair) to the matrix cores and "
-                "executes 12 vector instructions per pair (see executed_valu_tflops). profiles/microbench/valu_rates measures "
-                "131.8 TFLOP/s for a pure v_fma_f32 stream on this chip",
-                "executed_valu_tflops": 18.0 * B * n / (kern_ms * 1e-3) / 1e12,
-                # frac can exceed 1 against the vector peak alone because 24 of the 57 algorithmic flops per pair run on the
-                # matrix cores.  Ceiling with the matrix cores counted: the GEMM-shaped part of the reference's tests
-                # (E x1, E^T x2, H x1 = 32 flops per pair) hidden entirely behind the vector work, the other 25 flops at the
-                # float32 vector peak.
-                "combined_ceiling": {"peak": PEAK_FP32_VALU_TFLOPS * 57.0 / 25.0, "frac": achieved / (PEAK_FP32_VALU_TFLOPS * 57.0 / 25.0),
-                                     "valu_issue_frac_at_2p4GHz": 12.0 * B * n / 64 / 1024 / (kern_ms * 1e-3) / 1.2e9,
-                                     "mfma_busy_frac_at_2p4GHz": 6.0 * B * n / 1024 / 1024 * 32 / 2.4e9 / (kern_ms * 1e-3)},
-                "per_test": {"epipolar_only_kernel_ms": part_ms["epipolar"], "epipolar_evals_per_s": float(B) * n / (part_ms["epipolar"] * 1e-3),
-                             "transfer_only_kernel_ms": part_ms["transfer"], "transfer_evals_per_s": float(B) * n / (part_ms["transfer"] * 1e-3),
-                             "note": "each launch still solves both models"},
-                "loose_valu_kernel": {"kernel": "eh_upper_kernel<true>", "kernel_ms": loose_valu_ms,
-                                      "achieved": flops_per_launch / (loose_valu_ms * 1e-3) / 1e12,
-                                      "frac": flops_per_launch / (loose_valu_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS},
-                "tight_f32_kernel": {"kernel": "eh_upper_kernel<false>", "kernel_ms": tight_ms,
-                                     "achieved": flops_per_launch / (tight_ms * 1e-3) / 1e12,
-                                     "frac": flops_per_launch / (tight_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS},
-                "f64_kernel": {"kernel": "eh_score_kernel", "kernel_ms": f64_ms, "achieved": flops_per_launch / (f64_ms * 1e-3) / 1e12,
-                               "peak": PEAK_FP64_VALU_TFLOPS, "frac": flops_per_launch / (f64_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS},
-                "exact_mixed_kernel": {"kernel": "eh_score_mfma_kernel (the float64 counts of every hypothesis from matrix cores + float32, "
-                                       "float64 inside the error bands)", "kernel_ms": mixed_ms,
-                                       "achieved": flops_per_launch / (mixed_ms * 1e-3) / 1e12,
-                                       "counts_identical_to_f64_kernel": mixed_identical},
-            },
+            "roofline": roofline,
         }
+        if no_overlap_ms is not None:
+            out["no_overlap_ms_per_step"] = no_overlap_ms
+            out["no_overlap_value"] = evals_per_step / (no_overlap_ms * 1e-3)
         if args.cpu_sample > 0 and world == 1:
             base_res, idx_s, cE_s, cH_s = cpu_baseline(x1n, x2n, thr, n, idx_host[: args.cpu_sample])
             out["cpu_baseline"] = base_res
@@ -597,7 +814,7 @@ def main():
             }
         if world == 1 and not args.no_secondary:
             try:  # the headline line must print even if a side measurement fails
-                out["secondary"] = secondary_measurements(torch, ops, _capi, synthetic, args.seed)
+                out["secondary"] = secondary_measurements(torch, ops, _capi, synthetic, args.seed, table)
                 out["secondary"]["seed_sweep"] = seed_sweep(torch, ops, _capi, synthetic, orc, n, B)
             except Exception as e:  # noqa: BLE001
                 out["secondary"] = {"error": f"{type(e).__name__}: {e}"}

@@ -1,16 +1,34 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 (rocpd sqlite) outputs of profiles/run_profile.sh into a text summary.
+"""Turns the rocprofv3 (rocpd sqlite) outputs of profiles/run_profile.sh into a text summary and a machine-readable
+counter file (the latter is what bench.py reads its per-launch instruction counts and HBM traffic from).
 
-    python profiles/summarize.py gpurun_out/prof_<tag> > profiles/<tag>_summary.txt
+    python profiles/summarize.py gpurun_out/prof_<tag> [counters.json] > profiles/<tag>_summary.txt
+
+Counter values are per launch: the per-dispatch sum over all counter instances, averaged over the FULL-SIZE dispatches of a
+kernel (duration within a factor 2 of the median of that kernel's non-tiny dispatches), so the small launches the cascade makes with the same
+kernels (leader and candidate re-scores) do not dilute the figures.
 """
 import glob
+import json
 import os
 import sqlite3
 import sys
 
+MAIN = ("eh_upper", "eh_score", "t_score", "t_prep", "knn2", "lm_kernel", "argmax", "triangulate", "index_sets")
 
-def main(d):
+
+def full_size(vals):
+    """(value, duration) pairs of the full-size dispatches: within a factor 2 of the median duration of the dispatches that
+    are not tiny (the first, cold launch of a kernel can take three times as long and must not set the scale)."""
+    dmax = max(d for _, d in vals)
+    big = sorted(d for _, d in vals if d >= 0.1 * dmax)
+    ref = big[len(big) // 2]
+    return [(v, d) for v, d in vals if 0.5 * ref <= d <= 2.0 * ref]
+
+
+def main(d, json_out=None):
     tr = glob.glob(os.path.join(d, "trace", "*.db"))
+    counters = {}
     if tr:
         c = sqlite3.connect(tr[0])
         print("== kernel trace (rocprofv3 --kernel-trace --stats): name | calls | total us | avg us | % ==")
@@ -21,14 +39,15 @@ def main(d):
             rows = c.execute("select name, start, end from kernels order by start").fetchall()
             per = {}
             for name, st, en in rows:
-                if "eh_upper" in name or ("eh_score" in name) or "t_score" in name or "knn2_kernel" in name or "eh_solve" in name:
+                if any(k in name for k in MAIN[:6]):
                     per.setdefault(name[:80], []).append((en - st) / 1e3)
             for name, durs in per.items():
-                big = [x for x in durs if x > 0.25 * max(durs)]
+                big = [x for _, x in full_size([(0, x) for x in durs])]
                 print(f"{name:80s} | n={len(durs)} | full-size launches: " + " ".join(f"{x:.0f}" for x in big[:24]))
                 tail = big[-20:]
                 print(f"{'':80s} |   last {len(tail)} full-size launches (bench times these one at a time with events; earlier ones may "
                       f"overlap with another stream's launch): avg {sum(tail) / len(tail):.1f} us")
+                counters.setdefault(name, {})["trace_avg_us_last_full_size"] = sum(tail) / len(tail)
         except Exception as e:  # schema differences between rocprofv3 versions
             print("  (per-dispatch listing unavailable:", e, ")")
     for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
@@ -38,15 +57,26 @@ def main(d):
         if not dbs:
             continue
         c = sqlite3.connect(dbs[0])
-        print(f"\n== {os.path.basename(sub)} (rocprofv3 --pmc): per-kernel average over dispatches of the per-dispatch counter sum ==")
+        print(f"\n== {os.path.basename(sub)} (rocprofv3 --pmc): per-kernel average over FULL-SIZE dispatches of the per-dispatch counter sum ==")
         rows = c.execute(
-            "select name, counter_name, avg(v), count(*), avg(dur) from (select name, counter_name, dispatch_id, sum(counter_value) v, "
-            "max(duration) dur from pmc_events group by name, counter_name, dispatch_id) group by name, counter_name"
+            "select name, counter_name, dispatch_id, sum(counter_value) v, max(duration) dur from pmc_events group by name, counter_name, dispatch_id"
         ).fetchall()
-        for name, cn, v, n, dur in rows:
-            if "eh_upper" in name or "eh_score" in name or "eh_solve" in name or "t_score" in name or "argmax" in name or "lm_kernel" in name or "knn2" in name:
-                print(f"{name[:70]:70s} | {cn:22s} | {v:18.1f} | dispatches {n} | avg dur {dur/1e3:10.1f} us")
+        groups = {}
+        for name, cn, _, v, dur in rows:
+            groups.setdefault((name, cn), []).append((v, dur))
+        for (name, cn), vals in sorted(groups.items()):
+            if not any(k in name for k in MAIN):
+                continue
+            big = full_size(vals)
+            v = sum(x for x, _ in big) / len(big)
+            dur = sum(x for _, x in big) / len(big)
+            print(f"{name[:70]:70s} | {cn:26s} | {v:18.1f} | full-size dispatches {len(big)} of {len(vals)} | avg dur {dur / 1e3:10.1f} us")
+            counters.setdefault(name[:80], {})[cn] = v
+            counters[name[:80]][cn + "__dur_us"] = dur / 1e3
+    if json_out:
+        with open(json_out, "w") as f:
+            json.dump(counters, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
