@@ -709,7 +709,7 @@ def main():
         achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
         cnt, ind = ops.decode_best(best.cpu().numpy())
         table, counters_file = load_profile_counters(n, B)
-        dom = issue_roofline(kern_ms, kernel_counters(table, "eh_upper_mfma_kernel"))
+        dom = issue_roofline(kern_ms, kernel_counters(table, "eh_upper_mfma_kernel<true, true>"))
         exact = issue_roofline(mixed_ms, kernel_counters(table, "eh_score_mfma_kernel"))
         # Headline fraction: share of the chip's vector issue slots (at the 2.4 GHz spec clock) that the dominant kernel fills,
         # from its measured instruction count per launch and its duration measured here.  It cannot exceed 1.

@@ -261,20 +261,35 @@ int64_t sfm_t_ransac_mixed_workspace_bytes(const int64_t* cam_off, int32_t ncam)
 int sfm_t_ransac_mixed(const double* pts, const int64_t* cam_off, int32_t ncam, const int32_t* idx, int64_t nb, double thr,
                        void* workspace, int64_t workspace_bytes, int32_t* counts, uint64_t* best, double* T_best, void* stream);
 
-/* Record events of the E/H loop as ONE call each (launch-latency bound work: a handful of small kernels and one
- * read-back instead of a host round trip per step).  row: HOST int32[12], the index set of the recording iteration;
+/* Record events of the E/H loop as ONE call each: one kernel launch and one read-back (every workgroup repeats the
+ * short serial part - models of the sample, sign vote, decomposition, motion candidates - and handles its own matches).  row: HOST int32[12], the index set of the recording iteration;
  * scratch: device double[sfm_record_scratch_doubles()]; host_out: host double[same size]; both calls synchronise.
  * sfm_e_record_f64 = src/ransac_algorithm.py:105-113: E of the sample, its inlier mask over all matches (mask, device
  * uint8[n]) and essential_to_RT over ALL matches; host_out: E at 0..8, the four candidate [R|t] at 18..65 (row-major
  * 3x4 each), their chirality counts as int32[4] at double slot 66, the mask count as int32 at slot 68.
  * sfm_h_record_f64 = :121-147: H of the sample, homography_to_RT, and for each of its two solutions the epipolar
- * mask of E = [t]x R (mask_a / mask_b) and essential_to_RT over the masked matches; host_out additionally: H at 9..17,
+ * mask of E = [t]x R (mask_a / mask_b) and essential_to_RT over the masked matches; host_out (slots 0..8 unspecified): H at 9..17,
  * the homography_to_RT output at 70..112, the second solution's candidates at 113..160, counts at 161, mask count at 163. */
 int64_t sfm_record_scratch_doubles(void);
 int sfm_e_record_f64(const double* corr, int32_t n, const int32_t* row, double thr, uint8_t* mask, double* scratch,
                      double* host_out, void* stream);
 int sfm_h_record_f64(const double* corr, int32_t n, const int32_t* row, double thr, uint8_t* mask_a, uint8_t* mask_b,
                      double* scratch, double* host_out, void* stream);
+/* nev homography record events in one launch.  The positions of the H record events of a block of iterations are known
+ * as soon as its counts are (best_num_inliers_H only ever rises, src/ransac_algorithm.py:124-125: they are the strict
+ * running maxima of the H counts), so the loop's host side computes them all at once instead of one round trip each.
+ * rows: DEVICE int32[nev][12] (indices clamped into [0, n)); mask_a, mask_b: uint8[nev][n]; scratch (device) and
+ * host_out (host): double[nev][sfm_record_scratch_doubles()], each block laid out as for sfm_h_record_f64.  Synchronises. */
+int sfm_h_record_batch_f64(const double* corr, int32_t n, const int32_t* rows, int32_t nev, double thr, uint8_t* mask_a,
+                           uint8_t* mask_b, double* scratch, double* host_out, void* stream);
+
+/* ---- sample draws of the drop-in path (host only, no GPU involved) ---------------------------
+ * out[0..count) = what np.random.randint(0, n, size=count) returns for NumPy's legacy global generator in the state
+ * (key[624], *pos), which is advanced in place exactly as NumPy advances it: MT19937 words, each masked with the
+ * smallest 2^k - 1 >= n - 1 and redrawn while above n - 1 (n = 1 consumes nothing).  Replaces the draws of
+ * src/ransac_algorithm.py:94,116 and src/estimate_translation.py:64 at about 1 ns per integer instead of NumPy's
+ * 5-25 ns.  key and pos are HOST pointers (the package passes the address of NumPy's own state); n < 2^31. */
+int sfm_legacy_randint_fill(uint32_t* key, int32_t* pos, int64_t n, int64_t count, int32_t* out);
 
 /* ---- descriptor matching (feature front-end next to the path) ------------------------------
  * Replaces `cv2.BFMatcher().knnMatch(desc_query, desc_train, k=2)` followed by the ratio test

@@ -853,21 +853,6 @@ struct RowArg {
   int32_t v[12];
 };
 
-__global__ void models_from_row_kernel(const double4* __restrict__ corr, int n, RowArg row, double* __restrict__ E_out, double* __restrict__ H_out) {
-  double E[9], H[9];
-  double p8[8][4], p4[4][4];
-  gather_samples<double>(corr, n, row.v, p8, p4);
-  solve_E8<double>(p8, E);
-  solve_H4<double>(p4, H);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      E_out[i] = E[i];
-      H_out[i] = H[i];
-    }
-  }
-}
-
 template <bool kEpipolar>
 __global__ __launch_bounds__(kBlock) void mask_kernel(const double* __restrict__ M, const double4* __restrict__ corr, int n, double thr_arg,
                                                       uint8_t* __restrict__ mask, int* __restrict__ count) {
@@ -1007,6 +992,187 @@ __global__ __launch_bounds__(kBlock) void triangulate_kernel(const double* __res
   if (gid < m) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) X[(long long)i * m + j] = out[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// A record event of the E/H loop as ONE launch.  Every workgroup repeats the short serial part (model of the sample,
+// sign vote over all matches, decomposition, motion candidates: wave 0, the results handed to the other waves
+// through LDS) and then handles its own 256 matches (inlier masks, four triangulations per motion set, chirality
+// counts), so the event needs neither a second launch nor a grid-wide synchronisation.  Same device functions, same
+// operation order as the single-purpose kernels above: identical masks, counts and candidates.
+// scratch layout (doubles): E 0..8, H 9..17, P2s 18..65, rt 70..112, P2s of the second solution 113..160;
+// (int32) chirality counts at double slots 66 and 161, mask counts at 68 and 163; the launcher zeroes the counters.
+// ---------------------------------------------------------------------------------------
+constexpr int kRecE = 0, kRecH = 9, kRecP = 18, kRecCnt = 66, kRecMaskCnt = 68, kRecRt = 70, kRecP2 = 113, kRecCnt2 = 161, kRecMaskCnt2 = 163;
+constexpr int kRecDoubles = 256;
+
+// chirality counts of the four cameras P[0..3] (LDS) for this thread's match; adds the workgroup's counts to counts[0..3]
+__device__ __forceinline__ void chirality4_block(const double* __restrict__ P, const double4& p, bool live, int* __restrict__ counts) {
+  const double P1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  for (int c = 0; c < 4; ++c) {
+    double P2[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) P2[i] = P[12 * c + i];
+    double X[4];
+    triangulate_point<double>(P1, P2, p.x, p.y, p.z, p.w, X);
+    const double z2 = ((P2[8] * X[0] + P2[9] * X[1]) + P2[10] * X[2]) + P2[11] * X[3];
+    const double z1 = ((P1[8] * X[0] + P1[9] * X[1]) + P1[10] * X[2]) + P1[11] * X[3];
+    const int cnt = block_count(live && z2 > 0.0 && z1 > 0.0);
+    if (threadIdx.x == 0 && cnt) atomicAdd(counts + c, cnt);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void e_record_kernel(const double4* __restrict__ corr, int n, RowArg row, double two_thr_e2,
+                                                          uint8_t* __restrict__ mask, double* __restrict__ scratch) {
+  __shared__ double sE[9], sP[48];
+  if (threadIdx.x < 64) {  // wave 0, all lanes on the same sample
+    double E[9], H[9], P[4][12];
+    {
+      double p8[8][4], p4[4][4];
+      gather_samples<double>(corr, n, row.v, p8, p4);
+      solve_E8<double>(p8, E);
+      solve_H4<double>(p4, H);
+    }
+    essential_candidates<double>(E, P);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sE[i] = E[i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) sP[12 * c + i] = P[c][i];
+      if (blockIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          scratch[kRecE + i] = E[i];
+          scratch[kRecH + i] = H[i];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int i = 0; i < 12; ++i) scratch[kRecP + 12 * c + i] = P[c][i];
+      }
+    }
+  }
+  __syncthreads();
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const double4 p = corr[gid < n ? gid : n - 1];
+  double E[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) E[i] = sE[i];
+  const bool in = gid < n && epipolar_inlier<double>(E, p.x, p.y, p.z, p.w, two_thr_e2);
+  if (gid < n) mask[gid] = in ? 1 : 0;
+  const int c = block_count(in);
+  if (threadIdx.x == 0 && c) atomicAdd(reinterpret_cast<int*>(scratch + kRecMaskCnt), c);
+  chirality4_block(sP, p, gid < n, reinterpret_cast<int*>(scratch + kRecCnt));  // essential_to_RT over ALL matches (:110)
+}
+
+// grid = (match tiles, events).  Event e takes its index set from rows[e] (device memory) when rows is given, else
+// from `row`; its masks are mask_a/mask_b + e * n and its scratch block is scratch + e * kRecDoubles.
+__global__ __launch_bounds__(kBlock) void h_record_kernel(const double4* __restrict__ corr, int n, RowArg row, const int32_t* __restrict__ rows,
+                                                          double two_thr_e2, uint8_t* __restrict__ mask_a, uint8_t* __restrict__ mask_b,
+                                                          double* __restrict__ scratch) {
+  __shared__ double sH[9], sRt[43], sP[2][48];
+  __shared__ int votes;
+  if (rows) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) row.v[i] = rows[12 * blockIdx.y + i];
+  }
+  mask_a += (size_t)blockIdx.y * n;
+  mask_b += (size_t)blockIdx.y * n;
+  scratch += (size_t)blockIdx.y * kRecDoubles;
+  if (threadIdx.x == 0) votes = 0;
+  if (threadIdx.x < 64) {
+    double H[9];
+    {
+      double p8[8][4], p4[4][4];
+      gather_samples<double>(corr, n, row.v, p8, p4);
+      solve_H4<double>(p4, H);
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sH[i] = H[i];
+    }
+  }
+  __syncthreads();
+  {
+    // sign vote over ALL matches, repeated by every workgroup: sum(x2 * (H @ x1)) > 0, src/ransac_algorithm.py:359
+    double h[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h[i] = sH[i];
+    int mine = 0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      const double4 q = corr[j];
+      const double hx = (h[0] * q.x + h[1] * q.y) + h[2];
+      const double hy = (h[3] * q.x + h[4] * q.y) + h[5];
+      const double hz = (h[6] * q.x + h[7] * q.y) + h[8];
+      const double sgn = (q.z * hx + q.w * hy) + hz;
+      mine += sgn > 0.0 ? 1 : 0;
+    }
+    if (mine) atomicAdd(&votes, mine);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double h[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h[i] = sH[i];
+    const bool flip = (double)votes < (double)n / 2.0;
+    double R1[3][3], R2[3][3], t1[3], t2[3], Ea[9], Eb[9];
+    homography_decompose<double>(h, flip, R1, t1, R2, t2);
+    skew_times<double>(t1, R1, Ea);
+    skew_times<double>(t2, R2, Eb);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        sRt[i] = R1[i / 3][i % 3];
+        sRt[12 + i] = R2[i / 3][i % 3];
+        sRt[24 + i] = Ea[i];
+        sRt[33 + i] = Eb[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        sRt[9 + i] = t1[i];
+        sRt[21 + i] = t2[i];
+      }
+      sRt[42] = flip ? 1.0 : 0.0;
+    }
+    double P[4][12];
+    essential_candidates<double>(Ea, P);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) sP[0][12 * c + i] = P[c][i];
+    }
+    essential_candidates<double>(Eb, P);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) sP[1][12 * c + i] = P[c][i];
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 9) scratch[kRecH + threadIdx.x] = sH[threadIdx.x];
+    if (threadIdx.x < 43) scratch[kRecRt + threadIdx.x] = sRt[threadIdx.x];
+    if (threadIdx.x < 48) {
+      scratch[kRecP + threadIdx.x] = sP[0][threadIdx.x];
+      scratch[kRecP2 + threadIdx.x] = sP[1][threadIdx.x];
+    }
+  }
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const double4 p = corr[gid < n ? gid : n - 1];
+  for (int k = 0; k < 2; ++k) {  // the two solutions: epipolar mask of E = [t]x R, essential_to_RT over the masked matches (:133-147)
+    double E[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) E[i] = sRt[(k ? 33 : 24) + i];
+    const bool in = gid < n && epipolar_inlier<double>(E, p.x, p.y, p.z, p.w, two_thr_e2);
+    if (gid < n) (k ? mask_b : mask_a)[gid] = in ? 1 : 0;
+    const int c = block_count(in);
+    if (threadIdx.x == 0 && c) atomicAdd(reinterpret_cast<int*>(scratch + (k ? kRecMaskCnt2 : kRecMaskCnt)), c);
+    chirality4_block(sP[k], p, in, reinterpret_cast<int*>(scratch + (k ? kRecCnt2 : kRecCnt)));
   }
 }
 
@@ -2183,15 +2349,16 @@ int sfm_homography_to_rt_f64(const double* H, const double* corr, int32_t n, dou
   return check_launch();
 }
 
-// ---- record events of the E/H replay as one call each -----------------------------------
-// scratch layout (doubles): E 0..8, H 9..17, P2s 18..65, rt 70..112, P2s of the second solution 113..160;
-// (int32) chirality counts at double slots 66 and 161, mask counts at 68 and 163.
-namespace {
-constexpr int kRecE = 0, kRecH = 9, kRecP = 18, kRecCnt = 66, kRecMaskCnt = 68, kRecRt = 70, kRecP2 = 113, kRecCnt2 = 161, kRecMaskCnt2 = 163;
-constexpr int kRecDoubles = 256;
-}  // namespace
-
+// ---- record events of the E/H replay: one launch and one read-back each ------------------------
 int64_t sfm_record_scratch_doubles(void) { return kRecDoubles; }
+
+static int record_row(const int32_t* row, int32_t n, RowArg* r) {
+  for (int i = 0; i < 12; ++i) {
+    if (row[i] < 0 || row[i] >= n) return SFM_EINVAL;
+    r->v[i] = row[i];
+  }
+  return 0;
+}
 
 int sfm_e_record_f64(const double* corr, int32_t n, const int32_t* row, double thr, uint8_t* mask, double* scratch, double* host_out,
                      void* stream) {
@@ -2199,16 +2366,9 @@ int sfm_e_record_f64(const double* corr, int32_t n, const int32_t* row, double t
   if (!corr || !row || !mask || !scratch || !host_out || n <= 0) return SFM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   RowArg r;
-  for (int i = 0; i < 12; ++i) {
-    if (row[i] < 0 || row[i] >= n) return SFM_EINVAL;
-    r.v[i] = row[i];
-  }
+  SFM_TRY(record_row(row, n, &r));
   SFM_TRY(hipMemsetAsync(scratch + kRecCnt, 0, 4 * sizeof(double), st));
-  models_from_row_kernel<<<1, 64, 0, st>>>((const double4*)corr, n, r, scratch + kRecE, scratch + kRecH);
-  mask_kernel<true><<<div_up(n, kBlock), kBlock, 0, st>>>(scratch + kRecE, (const double4*)corr, n, 2.0 * thr * thr, mask,
-                                                        (int32_t*)(scratch + kRecMaskCnt));
-  essential_candidates_kernel<<<1, 64, 0, st>>>(scratch + kRecE, scratch + kRecP);
-  chirality4_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(scratch + kRecP, (const double4*)corr, nullptr, n, (int32_t*)(scratch + kRecCnt));
+  e_record_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>((const double4*)corr, n, r, 2.0 * thr * thr, mask, scratch);
   SFM_TRY(check_launch());
   SFM_TRY(hipMemcpyAsync(host_out, scratch, sizeof(double) * 70, hipMemcpyDeviceToHost, st));
   return (int)hipStreamSynchronize(st);
@@ -2220,25 +2380,26 @@ int sfm_h_record_f64(const double* corr, int32_t n, const int32_t* row, double t
   if (!corr || !row || !mask_a || !mask_b || !scratch || !host_out || n <= 0) return SFM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   RowArg r;
-  for (int i = 0; i < 12; ++i) {
-    if (row[i] < 0 || row[i] >= n) return SFM_EINVAL;
-    r.v[i] = row[i];
-  }
+  SFM_TRY(record_row(row, n, &r));
   SFM_TRY(hipMemsetAsync(scratch + kRecCnt, 0, 4 * sizeof(double), st));
   SFM_TRY(hipMemsetAsync(scratch + kRecCnt2, 0, 4 * sizeof(double), st));
-  models_from_row_kernel<<<1, 64, 0, st>>>((const double4*)corr, n, r, scratch + kRecE, scratch + kRecH);
-  homography_to_rt_kernel<<<1, 1024, 0, st>>>(scratch + kRecH, (const double4*)corr, n, scratch + kRecRt);
-  for (int k = 0; k < 2; ++k) {
-    const double* E = scratch + kRecRt + (k ? 33 : 24);
-    uint8_t* mask = k ? mask_b : mask_a;
-    double* P = scratch + (k ? kRecP2 : kRecP);
-    mask_kernel<true><<<div_up(n, kBlock), kBlock, 0, st>>>(E, (const double4*)corr, n, 2.0 * thr * thr, mask,
-                                                          (int32_t*)(scratch + (k ? kRecMaskCnt2 : kRecMaskCnt)));
-    essential_candidates_kernel<<<1, 64, 0, st>>>(E, P);
-    chirality4_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>(P, (const double4*)corr, mask, n, (int32_t*)(scratch + (k ? kRecCnt2 : kRecCnt)));
-  }
+  h_record_kernel<<<div_up(n, kBlock), kBlock, 0, st>>>((const double4*)corr, n, r, nullptr, 2.0 * thr * thr, mask_a, mask_b, scratch);
   SFM_TRY(check_launch());
   SFM_TRY(hipMemcpyAsync(host_out, scratch, sizeof(double) * 165, hipMemcpyDeviceToHost, st));
+  return (int)hipStreamSynchronize(st);
+}
+
+int sfm_h_record_batch_f64(const double* corr, int32_t n, const int32_t* rows, int32_t nev, double thr, uint8_t* mask_a, uint8_t* mask_b,
+                           double* scratch, double* host_out, void* stream) {
+  clear_stale_error();
+  if (!corr || !rows || !mask_a || !mask_b || !scratch || !host_out || n <= 0 || nev < 0 || nev > 65535) return SFM_EINVAL;
+  if (nev == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  SFM_TRY(hipMemsetAsync(scratch, 0, sizeof(double) * kRecDoubles * nev, st));
+  h_record_kernel<<<dim3(div_up(n, kBlock), nev), kBlock, 0, st>>>((const double4*)corr, n, RowArg{}, rows, 2.0 * thr * thr, mask_a, mask_b,
+                                                                  scratch);
+  SFM_TRY(check_launch());
+  SFM_TRY(hipMemcpyAsync(host_out, scratch, sizeof(double) * kRecDoubles * nev, hipMemcpyDeviceToHost, st));
   return (int)hipStreamSynchronize(st);
 }
 

@@ -61,8 +61,10 @@ _SIGS = {
     "sfm_record_scratch_doubles": (_c.c_int64, []),
     "sfm_e_record_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_double, _P, _P, _P, _P]),
     "sfm_h_record_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_double, _P, _P, _P, _P, _P]),
+    "sfm_h_record_batch_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int32, _c.c_double, _P, _P, _P, _P, _P]),
     "sfm_eh_upper_mfma_part_f32": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int32, _P,
                                               _P, _P]),
+    "sfm_legacy_randint_fill": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P]),
     "sfm_descriptors_to_i8": (_c.c_int, [_P, _c.c_int32, _c.c_int64, _P, _P, _P, _P]),
     "sfm_knn2_workspace_bytes": (_c.c_int64, [_c.c_int32, _c.c_int32]),
     "sfm_knn2_ratio_i8": (_c.c_int, [_P, _P, _c.c_int32, _P, _P, _c.c_int32, _c.c_double, _P, _c.c_int64, _P, _P, _P, _P, _P, _P]),

@@ -8,6 +8,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _capi as C
+from . import legacy_rng
 from . import ops
 from . import utils
 from .utils import log_execution_time
@@ -45,7 +46,8 @@ def robust_estimate_T_batch(cameras, K, pixel_threshold, num_iterations=NUM_ITER
     for s in range(0, len(cameras), MAX_CAMERAS_PER_LAUNCH):
         group = cameras[s : s + MAX_CAMERAS_PER_LAUNCH]
         sizes = [int(np.asarray(c[0]).shape[1]) for c in group]
-        idx = np.stack([np.random.randint(0, m, size=2 * num_iterations).reshape(num_iterations, 2) for m in sizes])
+        # == np.random.randint(0, m, size=2 * num_iterations) per camera, in camera order, from the global legacy stream
+        idx = np.stack([legacy_rng.randint(m, 2 * num_iterations).reshape(num_iterations, 2) for m in sizes])
         pts = torch.cat([_pack_camera(*c) for c in group])
         best, T, _ = ops.t_ransac(pts, sizes, C.dev(idx, np.int32), threshold)
         count, _ = ops.decode_best(best.cpu().numpy())

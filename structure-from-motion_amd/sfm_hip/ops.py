@@ -545,6 +545,23 @@ def h_record(corr, row, thr, scratch):
     return a, b
 
 
+def h_record_batch(corr, rows, thr):
+    """h_record for every row of `rows` (device int32 [k][12]) in one launch: a list of what h_record returns."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    n, k = corr.shape[0], rows.shape[0]
+    if k == 0:
+        return []
+    ma, mb = _empty((k, n), torch.uint8), _empty((k, n), torch.uint8)
+    nd = int(lib.sfm_record_scratch_doubles())
+    dev = _empty((k, nd), torch.float64)
+    host = np.zeros((k, nd), np.float64)
+    assert rows.dtype == torch.int32 and rows.is_contiguous() and rows.shape[1] == 12
+    C.check(lib.sfm_h_record_batch_f64(C.dptr(corr), n, C.dptr(rows), k, float(thr), C.dptr(ma), C.dptr(mb), C.dptr(dev), C.hptr(host),
+                                       C.stream_ptr()))
+    return [(_pick_candidate(host[e], 18, 66) + (ma[e],), _pick_candidate(host[e], 113, 161) + (mb[e],)) for e in range(k)]
+
+
 # ---- descriptor matching ---------------------------------------------------------------------
 
 

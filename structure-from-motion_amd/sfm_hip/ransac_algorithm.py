@@ -16,6 +16,7 @@ import time
 import numpy as np
 
 from . import _capi as C
+from . import legacy_rng
 from . import ops
 from .utils import normalize_K
 
@@ -52,18 +53,27 @@ class ReplayState:
         self.R = None
         self.T = None
         self.inliers = None
+        self.pending_E = None  # index row of the latest E record event whose R, T, inliers have not been computed yet
         self.events = []  # (iteration, 'E'|'H', accepted) for logging and tests
 
     def limit(self):
         return max(self.E_iters, self.H_iters)
 
 
-def replay_block(st, idx, cE, cH, backend):
+def replay_block(st, idx, cE, cH, backend, exact=None):
     """Advances the state machine over one block of hypotheses.
 
     idx: (nb,12) index sets, cE/cH: their inlier counts.  Returns the number of iterations of
-    the block the reference would have executed (== nb unless the loop ended inside it)."""
+    the block the reference would have executed (== nb unless the loop ended inside it).
+    exact (optional bool (nb,)): where False, cE/cH hold UPPER BOUNDS of the counts.  The loop only looks at counts
+    that exceed the running bests, so a bound at or below them is as good as the count; a bound above them is
+    replaced by the exact count (backend.refine) before it is used."""
     nb = idx.shape[0]
+    if hasattr(backend, "prefetch_h_records"):
+        # best_H only ever rises (:124-125), so the H record events of this block are the strict running maxima of cH
+        # above the incoming best_H, whatever the E branch does: they can all be computed before the replay starts
+        run = np.maximum.accumulate(np.concatenate([[st.best_H], cH]))
+        backend.prefetch_h_records(idx, np.flatnonzero(cH > run[:-1]))
     j = 0
     while j < nb:
         lim = st.limit()
@@ -73,6 +83,13 @@ def replay_block(st, idx, cE, cH, backend):
         else:
             k_stop = nb + 1
         ev = np.flatnonzero((cE[j:] > st.best_E) | (cH[j:] > st.best_H))
+        if exact is not None and ev.size and not exact[j + ev[0]]:
+            # (only after an accepted H record has LOWERED the best E count below the floor the bounds were filtered
+            # with: :150-154 / :161-165) every bound that now exceeds a running best becomes an exact count, in one call
+            todo = j + ev[~exact[j + ev]]
+            cE[todo], cH[todo] = backend.refine(todo)
+            exact[todo] = True
+            continue
         k_event = j + int(ev[0]) if ev.size else nb
         k_next = min(k_event, k_stop, nb)
         st.it += k_next - j
@@ -84,7 +101,9 @@ def replay_block(st, idx, cE, cH, backend):
         nE = int(cE[j])
         if nE > st.best_E:  # :105-113
             st.best_E = nE
-            st.R, st.T, st.inliers = backend.e_record(idx[j])
+            # R, T and the inlier mask of an E record are only ever read after the loop, and any later record
+            # overwrites them: the O(N) work (essential_to_RT over all matches, :110) is done once, for the last one
+            st.pending_E = np.array(idx[j])
             st.E_iters = ransac_iters(st.best_E / st.n, S_E)
             st.events.append((st.it, "E", True))
         nH = int(cH[j])
@@ -99,6 +118,7 @@ def replay_block(st, idx, cE, cH, backend):
                 if nb_ > nE:
                     pick = (Rb, Tb, nb_, mb)
             if pick is not None:
+                st.pending_E = None
                 st.R, st.T, st.best_E, st.inliers = pick
                 st.H_iters = ransac_iters(st.best_H / st.n, S_H)
                 st.E_iters = ransac_iters(st.best_E / st.n, S_E)
@@ -120,16 +140,24 @@ def run_replay(n, backend, chunk0=4096, chunk_max=1 << 18, max_iterations=None):
         nb = chunk if not np.isfinite(lim) else int(min(chunk, max(1, math.ceil(lim - st.it))))
         if max_iterations is not None:
             nb = max(1, min(nb, max_iterations - st.it))
-        rng_state = np.random.get_state()
-        idx = np.random.randint(0, n, size=12 * nb).reshape(nb, 12)
-        cE, cH = backend.score(idx)
-        used = replay_block(st, idx, cE, cH, backend)
+        rng_state = legacy_rng.mark()
+        idx = legacy_rng.randint(n, 12 * nb).reshape(nb, 12)  # == np.random.randint(0, n, size=12 * nb), same stream position after
+        exact = None
+        bounded = backend.score_bounded(idx, st.best_E, st.best_H) if hasattr(backend, "score_bounded") else None
+        if bounded is not None:
+            cE, cH, exact = bounded
+        else:
+            cE, cH = backend.score(idx)
+        used = replay_block(st, idx, cE, cH, backend, exact)
         if used < nb:
-            np.random.set_state(rng_state)
+            legacy_rng.rewind(rng_state)
             if used > 0:
-                np.random.randint(0, n, size=12 * used)
+                legacy_rng.randint(n, 12 * used)
             break
         chunk = min(chunk * 2, chunk_max)
+    if st.pending_E is not None:
+        st.R, st.T, st.inliers = backend.e_record(st.pending_E)
+        st.pending_E = None
     return st
 
 
@@ -152,8 +180,45 @@ class GpuBackend:
         self.n = self.corr.shape[0]
         self.scratch = ops.RecordScratch(self.n)
 
-    def score(self, idx):
+    MAX_PREFETCH = 64
+    BOUNDED_MIN_PAIRS = 1 << 28  # below this a block is scored exactly: the launch, not the arithmetic, is what costs
+
+    def score_bounded(self, idx, best_E, best_H):
+        """Block scoring driven by bounds (large blocks only): matrix-core UPPER bounds for every hypothesis, exact
+        float64 counts only for those whose bound exceeds a running best (the only ones the loop can ever look at).
+        Returns (cE, cH, exact) or None when exact scoring of the whole block is the better choice."""
+        import torch
+
+        nb = idx.shape[0]
+        if nb * self.n < self.BOUNDED_MIN_PAIRS or best_E <= 0 or best_H <= 0:
+            return None
         d_idx = C.dev(idx, np.int32)
+        if getattr(self, "corrm", None) is None:
+            self.corrm = ops.corr_to_mfma(self.corr, self.thr)
+        ue, uh = ops.eh_upper_mfma(self.corr, self.corrm, d_idx, self.thr, 3 * self.thr)
+        cand = torch.nonzero((ue > best_E) | (uh > best_H)).flatten()
+        if cand.shape[0] > nb // 8:
+            return None  # the bests are still low: nearly everything is a candidate
+        self.d_idx = d_idx
+        self.h_cache = {}
+        exact = np.zeros(nb, bool)
+        if cand.shape[0]:
+            xe, xh = ops.eh_score(self.corr, d_idx.index_select(0, cand), self.thr, 3 * self.thr)
+            ue[cand] = xe
+            uh[cand] = xh
+            exact[cand.cpu().numpy()] = True
+        return ue.cpu().numpy(), uh.cpu().numpy(), exact
+
+    def refine(self, positions):
+        """Exact counts of the given positions of the block scored last."""
+        import torch
+
+        xe, xh = ops.eh_score(self.corr, self.d_idx.index_select(0, torch.from_numpy(np.asarray(positions)).cuda()), self.thr, 3 * self.thr)
+        return xe.cpu().numpy(), xh.cpu().numpy()
+
+    def score(self, idx):
+        d_idx = self.d_idx = C.dev(idx, np.int32)
+        self.h_cache = {}
         # float64 counts; the residual tests run on the matrix cores + float32 with float64 inside the error band
         # (the library measures the coordinate range itself and evaluates everything in float64 when it is unusable)
         ce, ch = ops.eh_score_mixed(self.corr, d_idx, self.thr, 3 * self.thr)
@@ -163,9 +228,21 @@ class GpuBackend:
         """R, T of essential_to_RT over ALL points (src/ransac_algorithm.py:110) and the inlier mask: one library call."""
         return ops.e_record(self.corr, row, self.thr, self.scratch)
 
+    def prefetch_h_records(self, idx, positions):
+        """All H record events of the block just scored, in one launch and one read-back."""
+        import torch
+
+        positions = positions[: self.MAX_PREFETCH]
+        if positions.size == 0:
+            return
+        rows = self.d_idx.index_select(0, torch.from_numpy(positions).cuda())
+        for p, res in zip(positions, ops.h_record_batch(self.corr, rows, self.thr)):
+            self.h_cache[idx[p].tobytes()] = res
+
     def h_record(self, row):
-        """Both homography solutions scored as src/ransac_algorithm.py:128-147: one library call."""
-        return ops.h_record(self.corr, row, self.thr, self.scratch)
+        """Both homography solutions scored as src/ransac_algorithm.py:128-147 (prefetched with the block, else one call)."""
+        hit = self.h_cache.get(np.asarray(row).tobytes()) if hasattr(self, "h_cache") else None
+        return hit if hit is not None else ops.h_record(self.corr, row, self.thr, self.scratch)
 
 
 def estimate_E_robust(K, x1, x2, pixel_threshold):

@@ -38,6 +38,68 @@ def test_run_ransac_seeded_matches_reference(sfm, golden, tag):
     np.testing.assert_array_equal(np.random.randint(0, 2**31 - 1, size=4), g[f"{tag}_next_draws"])
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_run_ransac_bound_driven_blocks_match_reference(sfm, golden, tag, monkeypatch):
+    """The same seeded runs with block scoring driven by the matrix-core bounds from the second block on (the default
+    only switches to it for blocks of 2^28 pairs and more) and small blocks, so that several blocks are bounded."""
+    from sfm_hip import ransac_algorithm as ra
+
+    used = []
+    orig = ra.GpuBackend.score_bounded
+
+    def spy(self, idx, bE, bH):
+        out = orig(self, idx, bE, bH)
+        used.append(out is not None)
+        return out
+
+    monkeypatch.setattr(ra.GpuBackend, "BOUNDED_MIN_PAIRS", 0)
+    monkeypatch.setattr(ra.GpuBackend, "score_bounded", spy)
+    g = golden("eh_ransac.npz")
+    sc = two_view(g[f"{tag}_scene"])
+    np.random.seed(int(g[f"{tag}_seed"]))
+    x1, x2 = ra.normalize_K(sc["K"], sc["x1"]), ra.normalize_K(sc["K"], sc["x2"])
+    backend = ra.GpuBackend(x1, x2, 1.0 / sc["K"][0][0])
+    st = ra.run_replay(x1.shape[1], backend, chunk0=64, chunk_max=256)
+    assert any(used)
+    assert st.it == len(g[f"{tag}_cH"])
+    np.testing.assert_allclose(st.R, g[f"{tag}_R"], atol=1e-9)
+    np.testing.assert_allclose(np.reshape(st.T, (3, 1)), g[f"{tag}_T"], atol=1e-9)
+    np.testing.assert_array_equal(np.packbits(st.inliers.cpu().numpy().astype(bool)), g[f"{tag}_inliers"])
+    np.testing.assert_array_equal(np.random.randint(0, 2**31 - 1, size=4), g[f"{tag}_next_draws"])
+
+
+def test_h_record_batch_equals_single_records(sfm):
+    from sfm_hip import _capi as C
+    from sfm_hip import ops
+
+    sc = synthetic.two_view_scene(n=1300, inlier_ratio=0.6, planar_ratio=0.7, seed=8)
+    x1, x2 = orc.normalize_K(sc["K"], sc["x1"]), orc.normalize_K(sc["K"], sc["x2"])
+    corr = C.dev(ops.pack_corr(x1, x2))
+    thr = 1.0 / sc["K"][0][0]
+    rows = np.random.default_rng(3).integers(0, 1300, (9, 12)).astype(np.int32)
+    planar = np.flatnonzero(sc["is_inlier"])[:4]
+    rows[0, 8:] = planar  # one homography from true inliers
+    batch = ops.h_record_batch(corr, C.dev(rows), thr)
+    scratch = ops.RecordScratch(1300)
+    for e in range(9):
+        single = ops.h_record(corr, rows[e], thr, scratch)
+        for sol in range(2):
+            Rb, Tb, nb_, mb = batch[e][sol]
+            Rs, Ts, ns, ms = single[sol]
+            assert nb_ == ns and np.array_equal(Rb, Rs, equal_nan=True) and np.array_equal(Tb, Ts, equal_nan=True)
+            assert bool((mb == ms).all())
+    # and against the oracle for the good homography
+    H = orc.estimate_H_DLT(x1[:, planar], x2[:, planar])
+    Ra, Ta, Rb2, Tb2 = orc.homography_to_RT(H, x1, x2)
+    for R, T in ((Ra, Ta), (Rb2, Tb2)):  # the order of the two solutions follows the SVD's sign freedom: match them up
+        E = orc.skew_symmetric_mat(T) @ R
+        m = orc.epipolar_mask(E, x1, x2, thr)
+        Rr, Tr, cnt = orc.essential_to_RT(E, x1[:, m], x2[:, m])
+        hits = [g_ for g_ in batch[0] if g_[2] == cnt and bool((g_[3].cpu().numpy().astype(bool) == m).all())
+                and np.abs(g_[0] - Rr).max() < 1e-9 and np.abs(g_[1] - Tr).max() < 1e-9]
+        assert hits
+
+
 def test_estimate_R_three_pairs_vs_oracle(sfm):
     scs = [synthetic.two_view_scene(n=n, inlier_ratio=0.7, planar_ratio=0.6, seed=s, R=synthetic.rot_y(a))
            for n, s, a in ((500, 61, 0.08), (700, 62, -0.05), (400, 63, 0.12))]

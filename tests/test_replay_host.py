@@ -92,3 +92,91 @@ def test_record_event_candidate_choice_is_the_first_strict_maximum():
         R, T, n = ops._pick_candidate(host, 18, 66)
         assert n == counts[want]
         assert (R == P[want][:, :3]).all() and (T == P[want][:, 3]).all()
+
+
+class BoundedOracleBackend(OracleBackend):
+    """Block scoring driven by bounds, as the GPU backend does for large blocks: upper bounds (exact count + random
+    slack) everywhere, exact counts only where a bound exceeds a running best."""
+
+    def __init__(self, *a):
+        super().__init__(*a)
+        self.rng = np.random.default_rng(0)
+        self.refined = 0
+        self.bounded_blocks = 0
+
+    def score_bounded(self, idx, best_E, best_H):
+        if best_E <= 0 or best_H <= 0:
+            return None
+        self.bounded_blocks += 1
+        self.cur = orc.score_EH_batch(self.x1, self.x2, idx, self.thr)[:2]
+        ue = self.cur[0] + self.rng.integers(0, 40, idx.shape[0])
+        uh = self.cur[1] + self.rng.integers(0, 40, idx.shape[0])
+        exact = (ue > best_E) | (uh > best_H)
+        ue[exact] = self.cur[0][exact]
+        uh[exact] = self.cur[1][exact]
+        return ue, uh, exact
+
+    def refine(self, positions):
+        self.refined += len(positions)
+        return self.cur[0][positions], self.cur[1][positions]
+
+
+@pytest.mark.parametrize("tag,chunk0", [("a", 64), ("b", 16), ("c", 5), ("c", 32)])
+def test_bound_driven_replay_reproduces_reference_runs(golden, tag, chunk0):
+    g = golden("eh_ransac.npz")
+    n, inl, pl, seed = g[f"{tag}_scene"]
+    sc = synthetic.two_view_scene(n=int(n), inlier_ratio=float(inl), planar_ratio=float(pl), seed=int(seed))
+    x1 = orc.normalize_K(sc["K"], sc["x1"])
+    x2 = orc.normalize_K(sc["K"], sc["x2"])
+    np.random.seed(int(g[f"{tag}_seed"]))
+    be = BoundedOracleBackend(x1, x2, 1.0 / sc["K"][0][0])
+    st = run_replay(int(n), be, chunk0=chunk0)
+    assert be.bounded_blocks > 0
+    assert st.it == len(g[f"{tag}_cH"])
+    np.testing.assert_allclose(st.R, g[f"{tag}_R"], atol=1e-9)
+    np.testing.assert_allclose(np.reshape(st.T, (3, 1)), g[f"{tag}_T"], atol=1e-9)
+    np.testing.assert_array_equal(np.packbits(st.inliers), g[f"{tag}_inliers"])
+    np.testing.assert_array_equal(np.random.randint(0, 2**31 - 1, size=4), g[f"{tag}_next_draws"])
+
+
+def test_bound_driven_replay_refines_after_the_best_E_count_was_lowered():
+    """An accepted H record may LOWER the best E count (the reference compares with the current iteration's E count);
+    bounds that were filtered against the old best must then be replaced by exact counts before the loop reads them."""
+    from sfm_hip.ransac_algorithm import ReplayState, replay_block
+
+    class Scripted:
+        def __init__(self, true_e, true_h):
+            self.true_e, self.true_h, self.refined = true_e, true_h, []
+
+        def e_record(self, row):
+            return "R_E", "T_E", ("mask", int(row[0]))
+
+        def h_record(self, row):
+            return ("Ra", "Ta", 30, "ma"), ("Rb", "Tb", 10, "mb")  # solution a with 30 inliers wins if 30 > nE of that iteration
+
+        def refine(self, pos):
+            self.refined.extend(int(p) for p in pos)
+            return self.true_e[pos], self.true_h[pos]
+
+    def run(bounded):
+        st = ReplayState(1000)
+        st.best_E, st.best_H = 100, 50
+        st.E_iters = st.H_iters = 1e9
+        true_e = np.array([5, 3, 20, 45, 60, 7, 31, 2])
+        true_h = np.array([1, 60, 2, 3, 4, 5, 6, 7])  # position 1: H record; its E count 3 < 30: accepted, best_E drops to 30
+        idx = np.arange(8 * 12).reshape(8, 12)
+        be = Scripted(true_e, true_h)
+        if bounded:
+            ue = true_e + np.array([0, 0, 5, 40, 3, 10, 0, 90])  # bounds, all at or below the old best 100
+            exact = np.array([False, True, False, False, False, False, False, False])
+            used = replay_block(st, idx, ue.copy(), true_h.copy(), be, exact)
+        else:
+            used = replay_block(st, idx, true_e.copy(), true_h.copy(), be)
+        return st, used, be
+
+    a, ua, _ = run(False)
+    b, ub, be = run(True)
+    assert (ua, a.it, a.best_E, a.best_H, a.events) == (ub, b.it, b.best_E, b.best_H, b.events)
+    assert a.best_E == 60 and [e[1] for e in a.events] == ["H", "E", "E"]
+    assert be.refined  # bounds above 30 had to be made exact
+    assert a.pending_E is not None and (a.pending_E == b.pending_E).all()
