@@ -281,6 +281,42 @@ def secondary_measurements(torch, ops, _capi, synthetic, seed, table=None):
     return out
 
 
+def replay_throughput(torch, synthetic, orc, seed):
+    """The drop-in loop itself (sfm_hip.ransac_algorithm.run_replay = estimate_E_robust without the final unpacking) on a
+    long run: 200 000 matches, 15 % inliers (the adaptive limit stays far away), capped at 2 * 10^6 iterations.  Index sets
+    come from the global legacy np.random stream as in the reference; large blocks are scored through the matrix-core
+    bounds, exact counts only where a bound exceeds a running best.  The same run with exact scoring of every hypothesis
+    beside it; both must end in the same state."""
+    from sfm_hip import ransac_algorithm as ra
+
+    n, cap = 200000, 2000000
+    sc = synthetic.two_view_scene(n=n, inlier_ratio=0.15, planar_ratio=0.5, seed=seed + 3)
+    x1, x2 = orc.normalize_K(sc["K"], sc["x1"]), orc.normalize_K(sc["K"], sc["x2"])
+    thr = 1.0 / sc["K"][0][0]
+    out = {"workload": f"{n} matches, 15% inliers, {cap} iterations of the E/H loop, index sets from the legacy np.random stream"}
+    states = []
+    saved = ra.GpuBackend.BOUNDED_MIN_PAIRS
+    try:
+        for name, min_pairs in (("bound_driven", saved), ("exact_every_hypothesis", 1 << 62)):
+            ra.GpuBackend.BOUNDED_MIN_PAIRS = min_pairs
+            backend = ra.GpuBackend(x1, x2, thr)
+            np.random.seed(seed + 21)
+            ra.run_replay(n, backend, max_iterations=20000)  # warm-up: allocator, first launches
+            np.random.seed(seed + 22)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = ra.run_replay(n, backend, max_iterations=cap)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[name] = {"seconds": dt, "iterations": int(st.it), "evals_per_s": 2.0 * n * st.it / dt, "best_E": int(st.best_E),
+                         "best_H": int(st.best_H), "record_events": len(st.events)}
+            states.append((int(st.it), int(st.best_E), int(st.best_H), list(st.events), np.random.randint(0, 1 << 30)))
+    finally:
+        ra.GpuBackend.BOUNDED_MIN_PAIRS = saved
+    out["identical_final_state_and_stream_position"] = bool(states[0] == states[1])
+    return out
+
+
 def seed_sweep(torch, ops, _capi, synthetic, orc, n, B):
     """The headline step on scenes generated with seeds 0..4 (two steps in flight, 6 timed steps each): evals/s per
     seed and their median."""
@@ -360,15 +396,31 @@ def e2e(torch, synthetic, orc, seed, with_cpu):
     utils.find_correspondences = warm["find_correspondences"]
     np.random.seed(seed + 10)
     pipeline.run_geometry(warm["K"], warm["x_pairs"], warm["init_pair_dict"], warm["img_paths"], 1.0)  # library load, allocator
-    utils.find_correspondences = sc["find_correspondences"]
-    np.random.seed(seed + 11)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    got = pipeline.run_geometry(sc["K"], sc["x_pairs"], sc["init_pair_dict"], sc["img_paths"], 1.0)
-    torch.cuda.synchronize()
-    gpu_s = time.perf_counter() - t0
+    matcher = {"s": 0.0}
+
+    def timed_matcher(*a):
+        t = time.perf_counter()
+        r = sc["find_correspondences"](*a)
+        matcher["s"] += time.perf_counter() - t
+        return r
+
+    utils.find_correspondences = timed_matcher
+    best = None
+    for _ in range(3):
+        matcher["s"] = 0.0
+        np.random.seed(seed + 11)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = pipeline.run_geometry(sc["K"], sc["x_pairs"], sc["init_pair_dict"], sc["img_paths"], 1.0)
+        torch.cuda.synchronize()
+        gpu_s = time.perf_counter() - t0
+        if best is None or gpu_s < best[0]:
+            best = (gpu_s, matcher["s"])
+    gpu_s, match_s = best
     out = {"workload": "10 cameras, 6000 scene points, 4200 matches per consecutive pair, 4800 in the initial pair, 1 px threshold",
-           "gpu_seconds": gpu_s, "inliers_initial_pair": int(got["inliers"].sum())}
+           "gpu_seconds": gpu_s, "stand_in_matcher_seconds": match_s, "geometry_seconds": gpu_s - match_s,
+           "note": "best of 3 seeded repetitions (identical results); the stand-in matcher is host Python of the test scene, not part of the path",
+           "inliers_initial_pair": int(got["inliers"].sum())}
     if with_cpu:
         np.random.seed(seed + 11)
         t0 = time.perf_counter()
@@ -816,6 +868,7 @@ def main():
             try:  # the headline line must print even if a side measurement fails
                 out["secondary"] = secondary_measurements(torch, ops, _capi, synthetic, args.seed, table)
                 out["secondary"]["seed_sweep"] = seed_sweep(torch, ops, _capi, synthetic, orc, n, B)
+                out["secondary"]["drop_in_replay"] = replay_throughput(torch, synthetic, orc, args.seed)
             except Exception as e:  # noqa: BLE001
                 out["secondary"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
