@@ -1934,27 +1934,50 @@ static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n
   static const int span = getenv("SFM_HIP_EH_SPAN") ? atoi(getenv("SFM_HIP_EH_SPAN")) : 65536;
   if (span > 0 && tiles > 1 && splits < div_up(n, span)) splits = div_up(n, span);
   if (splits > ntiles) splits = ntiles;
-  const int tps = div_up(ntiles, splits);
-  if (splits > 1) {
-    hipError_t e = hipMemsetAsync(up_e, 0, sizeof(int32_t) * nb, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(up_h, 0, sizeof(int32_t) * nb, st);
-    if (e != hipSuccess) return (int)e;
-  }
   const uint4* pieces = (const uint4*)corrm;
   const float2* xy = (const float2*)((const char*)corrm + (size_t)npad * 32);
-  const dim3 grid((unsigned)tiles, splits);
   const double ke = 2.0 * thr_e * thr_e, kh = thr_h * thr_h;
-  if (part == 1)  // measurement only: the epipolar half alone (up_h receives zeros)
-    eh_upper_mfma_kernel<true, false><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, ke, kh, xmax, safety, up_e, up_h, tps,
-                                                               splits > 1);
-  else if (part == 2)  // measurement only: the transfer half alone
-    eh_upper_mfma_kernel<false, true><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, ke, kh, xmax, safety, up_e, up_h, tps,
-                                                               splits > 1);
-  else
-    eh_upper_mfma_kernel<true, true><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, ke, kh, xmax, safety, up_e, up_h, tps,
-                                                              splits > 1);
-  return check_launch();
+  // one launch over the hypothesis tiles [t_lo, t_hi) with the match range cut into `sp` pieces
+  auto launch = [&](long long t_lo, long long t_hi, int sp) -> int {
+    const long long off = t_lo * kBlock;
+    const long long cnt = (t_hi * kBlock < nb ? t_hi * kBlock : nb) - off;
+    const int tps = div_up(ntiles, sp);
+    if (sp > 1) {
+      SFM_TRY(hipMemsetAsync(up_e + off, 0, sizeof(int32_t) * cnt, st));
+      SFM_TRY(hipMemsetAsync(up_h + off, 0, sizeof(int32_t) * cnt, st));
+    }
+    const dim3 grid((unsigned)(t_hi - t_lo), sp);
+    if (part == 1)  // measurement only: the epipolar half alone (up_h receives zeros)
+      eh_upper_mfma_kernel<true, false><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, ke, kh, xmax, safety,
+                                                                 up_e + off, up_h + off, tps, sp > 1);
+    else if (part == 2)  // measurement only: the transfer half alone
+      eh_upper_mfma_kernel<false, true><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, ke, kh, xmax, safety,
+                                                                 up_e + off, up_h + off, tps, sp > 1);
+    else
+      eh_upper_mfma_kernel<true, true><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, ke, kh, xmax, safety,
+                                                                up_e + off, up_h + off, tps, sp > 1);
+    return check_launch();
+  };
+  // All workgroups do the same work, so a grid runs in rounds of as many workgroups as the chip holds at once, and a last
+  // round that is only a few percent full still takes a round.  When that happens the tiles of the last round are
+  // launched apart with their match range cut into pieces: as many workgroups as a full round, each a fraction of the work.
+  static const long long slots = [] {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0LL;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0LL;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, eh_upper_mfma_kernel<true, true>, kBlock, 0) != hipSuccess) return 0LL;
+    return (long long)cus * per_cu;
+  }();
+  static const bool cut_tail = !(getenv("SFM_HIP_EH_TAIL") && atoi(getenv("SFM_HIP_EH_TAIL")) == 0);
+  const long long rem = slots > 0 ? tiles % slots : 0;
+  if (cut_tail && splits == 1 && tiles > slots && rem > 0 && rem * 4 <= slots) {
+    int sp = (int)(slots / rem);
+    if (sp > 16) sp = 16;  // every piece solves its hypotheses again: keep that below the work it saves
+    if (sp > ntiles) sp = ntiles;
+    SFM_TRY(launch(0, tiles - rem, 1));
+    return launch(tiles - rem, tiles, sp);
+  }
+  return launch(0, tiles, splits);
 }
 
 int sfm_eh_upper_mfma_f32(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
