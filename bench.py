@@ -60,11 +60,18 @@ def load_profile_counters(matches, hyps):
         return json.load(f), os.path.relpath(files[-1], ROOT)
 
 
-def kernel_counters(table, needle):
+def kernel_counters(table, needle, per_call=False):
+    """per_call: counters summed over every launch of the kernel per full-size launch (a call of the dominant kernel may
+    cut its last, nearly empty round off as a second small launch; the duration measured here covers both)."""
     if not table:
         return {}
     for name, c in table.items():
         if needle in name and "SQ_INSTS_VALU" in c:
+            if per_call:
+                c = dict(c)
+                for k in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "FETCH_SIZE", "WRITE_SIZE"):
+                    if k + "__per_call" in c:
+                        c[k] = c[k + "__per_call"]
             return c
     return {}
 
@@ -761,7 +768,7 @@ def main():
         achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
         cnt, ind = ops.decode_best(best.cpu().numpy())
         table, counters_file = load_profile_counters(n, B)
-        dom = issue_roofline(kern_ms, kernel_counters(table, "eh_upper_mfma_kernel<true, true>"))
+        dom = issue_roofline(kern_ms, kernel_counters(table, "eh_upper_mfma_kernel<true, true>", per_call=True))
         exact = issue_roofline(mixed_ms, kernel_counters(table, "eh_score_mfma_kernel"))
         # Headline fraction: share of the chip's vector issue slots (at the 2.4 GHz spec clock) that the dominant kernel fills,
         # from its measured instruction count per launch and its duration measured here.  It cannot exceed 1.

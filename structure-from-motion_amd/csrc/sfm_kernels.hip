@@ -1392,14 +1392,29 @@ __global__ __launch_bounds__(kBlock) void t_prep_mfma_kernel(const double* __res
 __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* __restrict__ pts_all, const uint4* __restrict__ pieces,
                                                                  const unsigned* __restrict__ maxima, CamOffsets offs, CamPad pads,
                                                                  const int32_t* __restrict__ idx, long long nb, double thr2,
-                                                                 int* __restrict__ counts, int tiles_per_split, int use_atomics) {
+                                                                 int* __restrict__ counts, int tiles_per_split, int use_atomics,
+                                                                 int grid_tiles, int grid_cams, int grid_splits) {
   __shared__ uint4 bstage[kBlock / 64][64][3][2];
   __shared__ double tstage[kBlock / 64][64][3];
-  const int cam = blockIdx.y;
+  // grid_tiles == 0: a 3-D grid (hypothesis tile, camera, split).  Otherwise a 1-D grid of grid_tiles * grid_cams *
+  // grid_splits workgroups (grid_splits a multiple of 8) laid out so that linear ids that are equal modulo 8, which the
+  // dispatcher deals to the same XCD, work on the same eighth of the splits: every XCD's L2 then only ever holds its own
+  // correspondence ranges (a speed matter only: any placement gives the same counts).
+  int bx = blockIdx.x, cam = blockIdx.y, bz = blockIdx.z;
+  if (grid_tiles) {
+    const long long L = blockIdx.x;
+    const int xcd = (int)(L & 7);
+    const long long q = L >> 3;
+    const int per = grid_splits >> 3;
+    bz = (int)(q % per) * 8 + xcd;
+    const long long r = q / per;
+    bx = (int)(r % grid_tiles);
+    cam = (int)(r / grid_tiles);
+  }
   const double* __restrict__ pts = pts_all + 6 * offs.off[cam];
   const uint4* __restrict__ pc = pieces + 6 * pads.poff[cam];
   const int m = (int)(offs.off[cam + 1] - offs.off[cam]);
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long gid = (long long)bx * blockDim.x + threadIdx.x;
   const long long hyp = gid < nb ? gid : nb - 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
@@ -1441,7 +1456,7 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
   }
   const int apos = 16 * ((col >> 2) & 1) + (col & 3) + 4 * (col >> 3);  // see eh_upper_mfma_kernel
   const int ntiles = (m + 31) / 32;
-  const int t0 = blockIdx.z * tiles_per_split;
+  const int t0 = bz * tiles_per_split;
   const int t1 = min(ntiles, t0 + tiles_per_split);
   int cnt[2] = {0, 0};
   const f32x16 zero = {0};
@@ -2548,14 +2563,22 @@ int sfm_t_ransac_mixed(const double* pts, const int64_t* cam_off, int32_t ncam, 
   static const int span = getenv("SFM_HIP_T_SPAN") ? atoi(getenv("SFM_HIP_T_SPAN")) : 8192;
   if (span > 0 && tiles > 1 && splits < div_up(mmax, span)) splits = div_up(mmax, span);
   if (splits > ptiles) splits = ptiles;
+  // with 8 or more splits: a multiple of 8 of them and the XCD-aware 1-D grid (see the kernel)
+  static const bool xcd_grid = !(getenv("SFM_HIP_T_XCD") && atoi(getenv("SFM_HIP_T_XCD")) == 0);
+  const bool xcd = xcd_grid && splits >= 5 && ptiles >= 8 && tiles * ncam * ((splits + 7) / 8 * 8) <= 0x7FFFFFFFLL;
+  if (xcd) splits = (splits + 7) / 8 * 8 <= ptiles ? (splits + 7) / 8 * 8 : 8;
   const int tps = div_up(ptiles, splits);
   SFM_TRY(hipMemsetAsync(maxima, 0, 1024, st));
   if (splits > 1) SFM_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * nb * ncam, st));
   SFM_TRY(hipMemsetAsync(best, 0, sizeof(uint64_t) * ncam, st));
   t_prep_mfma_kernel<<<dim3(div_up(ptiles * 32, kBlock), ncam), kBlock, 0, st>>>(pts, offs, pads, thr, pieces, maxima);
   SFM_TRY(check_launch());
-  t_score_mfma_kernel<<<dim3((unsigned)tiles, ncam, splits), kBlock, 0, st>>>(pts, pieces, maxima, offs, pads, idx, nb, thr * thr, counts, tps,
-                                                                              splits > 1);
+  if (xcd)
+    t_score_mfma_kernel<<<dim3((unsigned)(tiles * ncam * splits)), kBlock, 0, st>>>(pts, pieces, maxima, offs, pads, idx, nb, thr * thr, counts,
+                                                                                    tps, 1, (int)tiles, ncam, splits);
+  else
+    t_score_mfma_kernel<<<dim3((unsigned)tiles, ncam, splits), kBlock, 0, st>>>(pts, pieces, maxima, offs, pads, idx, nb, thr * thr, counts, tps,
+                                                                                splits > 1, 0, 0, 0);
   SFM_TRY(check_launch());
   const int ablocks = (int)(tiles < 256 ? tiles : 256);
   argmax_kernel<<<dim3(ablocks, ncam), kBlock, 0, st>>>(counts, nb, 0ull, (unsigned long long*)best);
