@@ -1935,7 +1935,8 @@ int sfm_corr_to_mfma(const double* corr, int32_t n, double thr_e, void* corrm, v
 }
 
 static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
-                                double xmax, double safety, int32_t* up_e, int32_t* up_h, hipStream_t st, int part = 0) {
+                                double xmax, double safety, int32_t* up_e, int32_t* up_h, hipStream_t st, int part = 0,
+                                bool cut_last_round = true) {
   if (!corr || !corrm || !idx || !up_e || !up_h || n <= 0 || nb < 0 || ((uintptr_t)corrm & 15u) != 0) return SFM_EINVAL;
   if (!(xmax >= 0.0 && xmax < 1.0e300 && safety >= 1.0 && safety <= 1.0e3)) return SFM_EINVAL;
   if (nb == 0) return 0;
@@ -1975,7 +1976,9 @@ static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n
   };
   // All workgroups do the same work, so a grid runs in rounds of as many workgroups as the chip holds at once, and a last
   // round that is only a few percent full still takes a round.  When that happens the tiles of the last round are
-  // launched apart with their match range cut into pieces: as many workgroups as a full round, each a fraction of the work.
+  // launched apart with their match range cut into pieces: as many workgroups as a full round, each a fraction of the work
+  // (2-3 % for one call at a time; a caller that keeps several blocks in flight on several streams fills the last round
+  // with the next block's work anyway and is better off without the extra launch: cut_last_round = false).
   static const long long slots = [] {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0LL;
@@ -1985,7 +1988,7 @@ static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n
   }();
   static const bool cut_tail = !(getenv("SFM_HIP_EH_TAIL") && atoi(getenv("SFM_HIP_EH_TAIL")) == 0);
   const long long rem = slots > 0 ? tiles % slots : 0;
-  if (cut_tail && splits == 1 && tiles > slots && rem > 0 && rem * 4 <= slots) {
+  if (cut_tail && cut_last_round && splits == 1 && tiles > slots && rem > 0 && rem * 4 <= slots) {
     int sp = (int)(slots / rem);
     if (sp > 16) sp = 16;  // every piece solves its hypotheses again: keep that below the work it saves
     if (sp > ntiles) sp = ntiles;
@@ -2141,9 +2144,9 @@ int64_t sfm_eh_best_workspace_bytes(int64_t nb, int32_t n) {
 
 int64_t sfm_eh_best_pending_bytes(void) { return (int64_t)sizeof(BestPending); }
 
-int sfm_eh_best_submit(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
-                       double xmax, double safety, int32_t loose, void* workspace, int64_t workspace_bytes, void* host_pending,
-                       void* stream) {
+static int eh_best_submit(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
+                          double xmax, double safety, int32_t loose, void* workspace, int64_t workspace_bytes, void* host_pending,
+                          void* stream, bool blocks_in_flight) {
   clear_stale_error();
   if (!corr || !corr32 || !idx || !workspace || !host_pending || n <= 0 || nb <= 0 || (uint64_t)nb > 0x7FFFFFFFull) return SFM_EINVAL;
   BestWs w;
@@ -2152,7 +2155,7 @@ int sfm_eh_best_submit(const double* corr, const float* corr32, int32_t n, const
   // level 1: float32 bounds for every hypothesis, leaders, their exact counts, candidate lists
   if (loose == 2) {
     SFM_TRY(launch_corr_to_mfma(corr, n, thr_e, w.corrm, st));
-    SFM_TRY(launch_eh_upper_mfma(corr, w.corrm, n, idx, nb, thr_e, thr_h, xmax, safety, w.up_e, w.up_h, st));
+    SFM_TRY(launch_eh_upper_mfma(corr, w.corrm, n, idx, nb, thr_e, thr_h, xmax, safety, w.up_e, w.up_h, st, 0, !blocks_in_flight));
   } else {
     SFM_TRY(launch_eh_upper(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, loose, w.up_e, w.up_h, st));
   }
@@ -2174,6 +2177,12 @@ int sfm_eh_best_submit(const double* corr, const float* corr32, int32_t n, const
   SFM_TRY(check_launch());
   SFM_TRY(hipMemcpyAsync(host_pending, w.pending, sizeof(BestPending), hipMemcpyDeviceToHost, st));
   return 0;
+}
+
+int sfm_eh_best_submit(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
+                       double xmax, double safety, int32_t loose, void* workspace, int64_t workspace_bytes, void* host_pending,
+                       void* stream) {
+  return eh_best_submit(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, loose, workspace, workspace_bytes, host_pending, stream, true);
 }
 
 int sfm_eh_best_collect(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
@@ -2313,7 +2322,7 @@ int sfm_eh_best_collect(const double* corr, const float* corr32, int32_t n, cons
 int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax,
                 double safety, int32_t loose, void* workspace, int64_t workspace_bytes, int64_t* result, void* stream) {
   static thread_local BestPending pending;  // pageable: the copy into it completes before hipMemcpyAsync returns or at the sync below
-  SFM_TRY(sfm_eh_best_submit(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, loose, workspace, workspace_bytes, &pending, stream));
+  SFM_TRY(eh_best_submit(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, loose, workspace, workspace_bytes, &pending, stream, false));
   return sfm_eh_best_collect(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, loose, workspace, workspace_bytes, &pending, result,
                              stream);
 }
