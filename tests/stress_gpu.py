@@ -1,4 +1,4 @@
-"""Randomised exactness sweep (run by hand on the GPU box, not collected by pytest):
+"""Randomised exactness sweep (the long form is run by hand on the GPU box; tests/test_gpu_stress.py runs a slice):
 
     python tests/stress_gpu.py [n_configs] > profiles/<tag>_stress.txt
 
@@ -23,9 +23,9 @@ from oracle import sfm_oracle as orc  # noqa: E402
 from sfm_hip import _capi, ops, synthetic  # noqa: E402
 
 
-def main(n_cfg):
+def main(n_cfg, seed=2024):
     _capi.load_library()
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(seed)
     bad = 0
     t_start = time.time()
     pairs_eh = pairs_t = 0
@@ -35,7 +35,7 @@ def main(n_cfg):
         inl = float(rng.choice([0.0, 0.05, 0.3, 0.6, 0.95]))
         pl = float(rng.choice([0.0, 0.5, 1.0]))
         px = float(rng.choice([0.5, 1.0, 3.0]))
-        sc = synthetic.two_view_scene(n=n, inlier_ratio=inl, planar_ratio=pl, seed=1000 + c)
+        sc = synthetic.two_view_scene(n=n, inlier_ratio=inl, planar_ratio=pl, seed=seed + 1000 + c)
         thr = px / sc["K"][0][0]
         x1n = orc.normalize_K(sc["K"], sc["x1"])
         x2n = orc.normalize_K(sc["K"], sc["x2"])
