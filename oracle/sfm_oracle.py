@@ -575,3 +575,19 @@ def run_geometry(K, x_pairs, init_pair_dict, img_paths, pixel_threshold, find_co
     est = estimate_translation(K, desc_X, X0, abs_rot, img_paths, pixel_threshold, find_correspondences)
     ref = refine_translation(K, img_paths, desc_X[:, inliers], X0, abs_rot, est, find_correspondences)
     return {"absolute_rotations": abs_rot, "refined_Ts": ref, "X0": X0, "inliers": inliers, "estimated_Ts": est}
+
+
+def camera_centres_and_axes(P_list):
+    """utils.py:92-102 of the reference's visualiser: the centre of every camera is the null vector of its 3x4
+    matrix divided by its last entry, the drawn viewing direction is P[2, 0:3]."""
+    from scipy.linalg import null_space
+
+    c = np.zeros((4, len(P_list)))
+    v = np.zeros((3, len(P_list)))
+    for i, P in enumerate(P_list):
+        ns = null_space(P)
+        if ns.size:
+            c[:, i] = ns[:, 0]
+        v[:, i] = P[2, 0:3]
+    c = c / c[3, :]
+    return c[:3], v

@@ -89,3 +89,14 @@ def test_cli_driver_writes_reference_compatible_results(tmp_path, monkeypatch):
         Xr = orc.filter_3D_points(orc.triangulate_3D_point_DLT([P1, P2], [sc["x_pairs"][2 * i], sc["x_pairs"][2 * i + 1]]))
         assert X.shape == Xr.shape
         np.testing.assert_allclose(X, Xr, rtol=1e-5, atol=1e-6)  # stated bar for 3D points: 1e-5 relative
+    # the visualiser's command line reads the same file and writes the animation (the reference's 120 frames cut to 3 here)
+    from PIL import Image
+
+    import visualization as vis
+    from sfm_hip import render
+
+    monkeypatch.setattr(render, "FRAME_STEP_DEGREES", 120)
+    gif = vis.visualize_results(["--dataset", "syn"])
+    assert gif == "output/rotation_dataset_syn.gif"
+    with Image.open(tmp_path / gif) as im:
+        assert im.n_frames == 3
