@@ -1309,10 +1309,19 @@ __global__ __launch_bounds__(kBlock) void t_upper_kernel(const double* __restric
 // d = dx^2 + dy^2 - q^2 then decides the pair by its sign unless |d| <= delta, the rigorous bound of
 // its distance from the float64 value near the threshold: with r = |(dx, dy)| and e the bound of
 // |r_c - r| + |q_c - q|, a pair with |r - |q|| > e is decided correctly by the sign of r_c - |q_c|,
-// and any other pair has |d_c| <= 4 e |q_c| + 4 e^2 (+ float32 rounding of d_c) = delta.  Pairs inside
-// the band (about one in 10^6) are re-evaluated with the float64 test of t_score_kernel on the spot,
-// so the counts are identical to t_score_kernel's for every hypothesis.
+// and any other pair has |d_c| <= 4 e |q_c| + 4 e^2 (+ float32 rounding of d_c) <= delta, where delta takes
+// |q_c| at its bound over the camera's correspondences and is therefore ONE constant per hypothesis: the inner
+// loop only keeps the smallest |d_c| of a register row (half a v_min3 per pair) and compares it with delta once per
+// 16 pairs.  Pairs inside the band (about one in 10^6) are then found and re-evaluated with the float64 test of
+// t_score_kernel on the spot, so the counts are identical to t_score_kernel's for every hypothesis.
 // ---------------------------------------------------------------------------------------
+// min(m, |a|, |b|) in one instruction (m >= 0); a NaN operand is ignored, as by fminf
+__device__ __forceinline__ float min3_abs(float m, float a, float b) {
+  float r;
+  asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
+}
+
 struct CamPad {
   int64_t poff[kMaxCams + 1];  // offsets of the cameras in the padded (multiple of 32) point numbering
 };
@@ -1418,7 +1427,7 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
   const long long hyp = gid < nb ? gid : nb - 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
-  float c1_own, c0_own;
+  float band_own;
   {
     const int32_t* pair = idx + 2 * ((long long)cam * nb + hyp);
     double T[3];
@@ -1430,15 +1439,17 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
 #pragma unroll
     for (int i = 0; i < 3; ++i) tstage[wave][lane][i] = T[i];
     const double tmax = fmax(fabs(T[0]), fmax(fabs(T[1]), fabs(T[2])));
-    const bool usable = tmax < 1.0e6;  // false for NaN / infinite / absurd translations: those are scored entirely in float64
+    bool usable = tmax < 1.0e6;  // false for NaN / infinite / absurd translations: those are scored entirely in float64
     const double thr = sqrt(thr2);
     const double amax = __uint_as_float(maxima[4 * cam]), bmax = __uint_as_float(maxima[4 * cam + 1]);
     const double zmax = __uint_as_float(maxima[4 * cam + 2]), uvmax = __uint_as_float(maxima[4 * cam + 3]);
     const double Rx = amax + fabs(T[0]) + uvmax * fabs(T[2]), Ry = bmax + fabs(T[1]) + uvmax * fabs(T[2]);
     const double Rq = thr * (zmax + fabs(T[2]));
+    usable = usable && Rx + Ry + Rq < 1.0e15;  // beyond that the float32 squares could overflow (false for NaN as well)
     const double e = 2.0 * kEpsMfma * (Rx + Ry + Rq);  // bound of |r_c - r| + |q_c - q|, doubled
-    c1_own = usable ? round_up_f32(4.0 * e + 13.0 * kEps32 * Rq * 1.001) : 0.0f;
-    c0_own = usable ? round_up_f32(4.1 * e * e) : __builtin_inff();
+    // |d_c| of a pair that the float32 sign may get wrong is below (4 e + 13 eps Rq) |q_c| + 4.1 e^2, and |q_c| <= Rq + e
+    const double c1 = 4.0 * e + 13.0 * kEps32 * Rq * 1.001;
+    band_own = usable ? round_up_f32((c1 * (Rq * 1.000001 + e) + 4.1 * e * e) * 1.000001) : __builtin_inff();
     const double tx = usable ? T[0] : 0.0, ty = usable ? T[1] : 0.0, tz = usable ? T[2] : 0.0;
     pack_t_vector(true, 0.0, false, tx, true, tz, true, bstage[wave][lane][0][0], bstage[wave][lane][0][1]);
     pack_t_vector(true, 0.0, false, ty, true, tz, true, bstage[wave][lane][1][0], bstage[wave][lane][1][1]);
@@ -1446,13 +1457,12 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
   }
   __syncthreads();
   bf16x8 B[2][3];
-  float c1[2], c0[2];
+  float band[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
 #pragma unroll
     for (int v = 0; v < 3; ++v) B[k][v] = as_bf16x8(bstage[wave][32 * k + col][v][half]);
-    c1[k] = __shfl(c1_own, 32 * k + col);
-    c0[k] = __shfl(c0_own, 32 * k + col);
+    band[k] = __shfl(band_own, 32 * k + col);
   }
   const int apos = 16 * ((col >> 2) & 1) + (col & 3) + 4 * (col >> 3);  // see eh_upper_mfma_kernel
   const int ntiles = (m + 31) / 32;
@@ -1470,17 +1480,26 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
       const f32x16 dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ax, B[k][0], zero, 0, 0, 0);
       const f32x16 dy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay, B[k][1], zero, 0, 0, 0);
       const f32x16 q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq, B[k][2], zero, 0, 0, 0);
-      unsigned hneg = 0, hamb = 0;
+      unsigned hneg = 0;
+      float closest = __builtin_inff();  // the smallest |d| of this lane's 16 pairs
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float d = fma(-q[i], q[i], fma(dy[i], dy[i], dx[i] * dx[i]));  // < 0 <=> inlier
-        hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d), 31);
-        const float a = fabsf(d) - fma(c1[k], fabsf(q[i]), c0[k]);  // < 0 <=> the float32 sign is not trusted
-        hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(a), 31);
+      for (int i = 0; i < 16; i += 2) {
+        const float d0 = fma(-q[i], q[i], fma(dy[i], dy[i], dx[i] * dx[i]));  // < 0 <=> inlier
+        const float d1 = fma(-q[i + 1], q[i + 1], fma(dy[i + 1], dy[i + 1], dx[i + 1] * dx[i + 1]));
+        hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d0), 31);
+        hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d1), 31);
+        closest = min3_abs(closest, d0, d1);
       }
-      unsigned amb = hamb & vmask;
-      cnt[k] += __popc(hneg & vmask & ~amb);
-      if (amb) {
+      cnt[k] += __popc(hneg & vmask);
+      if (closest <= band[k]) {  // rare: some pair of this row is too close to the threshold for its float32 sign (or is padding)
+        unsigned hamb = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float d = fma(-q[i], q[i], fma(dy[i], dy[i], dx[i] * dx[i]));  // the same instructions give the same value again
+          hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(d) - band[k]), 31);  // <= 0 would be exact; < 0 after the inflation of band
+        }
+        unsigned amb = band[k] == __builtin_inff() ? vmask : (hamb & vmask);  // an unusable hypothesis takes the float64 test everywhere
+        cnt[k] -= __popc(hneg & amb);  // take the untrusted signs back out
         const double* T = tstage[wave][32 * k + col];
         const double T0 = T[0], T1 = T[1], T2 = T[2];
         while (amb) {
