@@ -23,6 +23,7 @@ timed region (--no-overlap runs them strictly one after the other).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -60,18 +61,31 @@ def load_profile_counters(matches, hyps):
         return json.load(f), os.path.relpath(files[-1], ROOT)
 
 
-def kernel_counters(table, needle, per_call=False):
+def kernel_counters(table, needle, per_call=False, kernel_ms=None):
     """per_call: counters summed over every launch of the kernel per full-size launch (a call of the dominant kernel may
-    cut its last, nearly empty round off as a second small launch; the duration measured here covers both)."""
+    cut its last, nearly empty round off as a second small launch; the duration measured here covers both).
+    kernel_ms: the launch duration measured in this run; one kernel serves several workloads of the profiled command, so the
+    counters are taken from the group of profiled launches whose duration is within 1.4x of it, and there are none
+    ({}: no issue figures rather than those of another workload) when the profile holds no such group."""
     if not table:
         return {}
     for name, c in table.items():
         if needle in name and "SQ_INSTS_VALU" in c:
+            c = dict(c)
             if per_call:
-                c = dict(c)
                 for k in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "FETCH_SIZE", "WRITE_SIZE"):
                     if k + "__per_call" in c:
                         c[k] = c[k + "__per_call"]
+            elif kernel_ms is not None:
+                groups = c.get("__clusters")
+                if groups is None:  # a counters file without duration groups: usable only if its full-size launches match
+                    ok = 1 / 1.4 <= c.get("SQ_INSTS_VALU__dur_us", 0.0) / (kernel_ms * 1e3) <= 1.4
+                    return c if ok else {}
+                for k, rows in groups.items():
+                    near = min(rows, key=lambda r: abs(math.log(r[0] / (kernel_ms * 1e3))))
+                    if not 1 / 1.4 <= near[0] / (kernel_ms * 1e3) <= 1.4:
+                        return {}
+                    c[k], c[k + "__dur_us"] = near[1], near[0]
             return c
     return {}
 
@@ -234,7 +248,7 @@ def secondary_measurements(torch, ops, _capi, synthetic, seed, table=None):
             "unit": "TFLOP/s",
             "frac": FLOPS_PER_T_EVAL * ncam * float(m) * B / (ms_mixed * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
             "flops_per_eval": FLOPS_PER_T_EVAL,
-            "issue": issue_roofline(ms_mixed, kernel_counters(table, "t_score_mfma_kernel")),
+            "issue": issue_roofline(ms_mixed, kernel_counters(table, "t_score_mfma_kernel", kernel_ms=ms_mixed)),
         },
     }
     # C4-like: LM (10 iterations, mu = 0.01) and triangulation with per-camera sizes 1e2..1e4
@@ -769,7 +783,7 @@ def main():
         cnt, ind = ops.decode_best(best.cpu().numpy())
         table, counters_file = load_profile_counters(n, B)
         dom = issue_roofline(kern_ms, kernel_counters(table, "eh_upper_mfma_kernel<true, true>", per_call=True))
-        exact = issue_roofline(mixed_ms, kernel_counters(table, "eh_score_mfma_kernel"))
+        exact = issue_roofline(mixed_ms, kernel_counters(table, "eh_score_mfma_kernel", kernel_ms=mixed_ms))
         # Headline fraction: share of the chip's vector issue slots (at the 2.4 GHz spec clock) that the dominant kernel fills,
         # from its measured instruction count per launch and its duration measured here.  It cannot exceed 1.
         roofline = {

@@ -26,6 +26,20 @@ def full_size(vals):
     return [(v, d) for v, d in vals if 0.5 * ref <= d <= 2.0 * ref]
 
 
+def clusters(vals):
+    """[average duration (us), average value, launches] of every group of dispatches with similar durations (sorted by
+    duration, a new group where the duration grows by more than 1.5x): one kernel serves several workloads of one run,
+    and a reader that timed one of them picks the group that matches its own time."""
+    out, cur = [], []
+    for v, dur in sorted(vals, key=lambda x: x[1]):
+        if cur and dur > 1.5 * cur[0][1]:
+            out.append(cur)
+            cur = []
+        cur.append((v, dur))
+    out.append(cur)
+    return [[sum(d_ for _, d_ in g) / len(g) / 1e3, sum(v for v, _ in g) / len(g), len(g)] for g in out]
+
+
 def main(d, json_out=None):
     tr = glob.glob(os.path.join(d, "trace", "*.db"))
     counters = {}
@@ -77,6 +91,7 @@ def main(d, json_out=None):
             # second, small launch of the same kernel is then priced whole (longer dispatches belong to other workloads)
             small = [x for x, d_ in vals if d_ < 0.5 * min(d for _, d in big)]
             counters[name[:80]][cn + "__per_call"] = (sum(x for x, _ in big) + sum(small)) / len(big)
+            counters[name[:80]].setdefault("__clusters", {})[cn] = clusters(vals)
     if json_out:
         with open(json_out, "w") as f:
             json.dump(counters, f, indent=1, sort_keys=True)

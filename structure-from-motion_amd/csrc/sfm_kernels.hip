@@ -420,6 +420,13 @@ __global__ __launch_bounds__(kBlock) void corr_to_mfma_kernel(const double4* __r
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
+// min(m, |a|, |b|) in one instruction (m >= 0); a NaN operand is ignored, as by fminf
+__device__ __forceinline__ float min3_abs(float m, float a, float b) {
+  float r;
+  asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
+}
+
 template <bool kDoE, bool kDoH>
 __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
                                                                   const float2* __restrict__ xy, int n, const int32_t* __restrict__ idx,
@@ -576,12 +583,14 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
 // EXACT E/H counts (those of eh_score_kernel) at matrix-core + float32 cost: the scheme of
 // t_score_mfma_kernel applied to both tests.  Rows l = E x1, (m0, m1) = (E^T x2)_{0,1} and h = H x1 come
 // from bf16 MFMAs of three-piece splits; the float32 values
-//     dE = s^2 (n1 + n2) - k n1 n2        and        dH = dx^2 + dy^2 - (sqrt(T) hz)^2
-// decide a pair by their sign unless they lie inside a rigorous band around zero:
-//   epipolar: with f = |s| - sqrt(k) g(L1, L2) (g = L1 L2 / sqrt(L1^2 + L2^2), 1-Lipschitz in L1 and L2) the computed
-//   f_c is within G = Es + sqrt(k)(eL1 + eL2) of f and dE_c = (n1 + n2) f_c (|s_c| + sqrt(k) g_c); a pair with
-//   |f| <= G therefore has |dE_c| <= 4 G sqrt(k) sqrt(n1 n2 (n1 + n2)) + 4 G^2 (n1 + n2) (+ float32 rounding);
-//   transfer: as in t_score_mfma_kernel with r = |(dx, dy)| and q = sqrt(T) hz.
+//     fE = |s| - sqrt(k) g,  g = sqrt(n1 n2 / (n1 + n2))        and        dH = dx^2 + dy^2 - (sqrt(T) hz)^2
+// decide a pair by their sign unless they lie inside a rigorous band around zero, and each band is ONE constant per
+// hypothesis, so the inner loops only keep the smallest |fE| / |dH| of a register row (half a v_min3 per pair) and
+// look for the untrusted pairs of a row only when that minimum trips the band:
+//   epipolar: the reference's test mean(d1^2, d2^2) < thr^2 is fE < 0 (k = 2 thr^2); g = L1 L2 / sqrt(L1^2 + L2^2) is
+//   1-Lipschitz in the line norms L1, L2 and at most min(L1, L2), so the computed fE_c is within
+//   Es + sqrt(k)(eL1 + eL2) + (float32 evaluation of g and of the final fma) of fE;
+//   transfer: as in t_score_mfma_kernel with r = |(dx, dy)| and q = sqrt(T) hz, |q| taken at its bound over all matches.
 // Pairs inside a band are re-evaluated with the float64 tests of eh_score_kernel (models parked in LDS).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void corr_to_mfma2_kernel(const double4* __restrict__ corr, int n, int npad, uint4* __restrict__ pieces,
@@ -602,21 +611,27 @@ __global__ __launch_bounds__(kBlock) void corr_to_mfma2_kernel(const double4* __
   publish_absmax(c, j < n, reinterpret_cast<unsigned*>(xy + npad));  // 16-byte trailer, zeroed by the launcher
 }
 
-__global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
-                                                                  const float2* __restrict__ xy, int n, const int32_t* __restrict__ idx,
-                                                                  long long nb, double two_thr_e2, double thr_h2, double xmax,
-                                                                  int* __restrict__ count_e, int* __restrict__ count_h,
-                                                                  int tiles_per_split, int use_atomics) {
+// kDoE / kDoH: which of the two counts this instantiation produces (the other model is neither solved nor scored, its
+// count array is not touched); the split forms need fewer registers and run at a higher occupancy (kMinBlocks).
+template <bool kDoE, bool kDoH, int kMinBlocks>
+__global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
+                                                                           const float2* __restrict__ xy, int n,
+                                                                           const int32_t* __restrict__ idx, long long nb, double two_thr_e2,
+                                                                           double thr_h2, double xmax, int* __restrict__ count_e,
+                                                                           int* __restrict__ count_h, int tiles_per_split, int use_atomics) {
+  constexpr int kVecE = kDoE ? 5 : 0, kVec = kVecE + (kDoH ? 3 : 0);  // piece vectors per hypothesis: E rows 0-2, E columns 0-1, H rows 0-2
+  constexpr int kModel = 9 * ((kDoE ? 1 : 0) + (kDoH ? 1 : 0));       // doubles per hypothesis parked for the float64 re-evaluation
+  static_assert(kModel * 8 <= kVec * 32, "the parked models reuse the staging area of the piece vectors");
   __shared__ unsigned char fin[kBlock / 64][64];
-  __shared__ uint4 bstage[kBlock / 64][64][8][2];
+  __shared__ uint4 bstage[kBlock / 64][64][kVec][2];
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long hyp = gid < nb ? gid : nb - 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, half = lane >> 5;
   const double safety = 2.0;
   const double xm = usable_xmax(xmax, *reinterpret_cast<const unsigned*>(xy + ((n + 31) / 32) * 32));
-  const bool all_f64 = !(xm < 1.0e6);  // no usable coordinate bound: every pair takes the float64 test
-  float ca_own, cb_own, c1_own, c0_own;
+  const bool all_f64 = !(xm < 1.0e5);  // no usable coordinate bound (or float32 products that could overflow): every pair takes the float64 test
+  float ge_own = 0.0f, gh_own = 0.0f;
   double Ed[9], Hd[9];
   {
     double A[9];
@@ -624,60 +639,63 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
     {
       double p8[8][4], p4[4][4];
       gather_samples<double>(corr, n, idx + 12 * hyp, p8, p4);
-      solve_E8<double>(p8, Ed);
-      solve_H4<double>(p4, Hd);
+      if constexpr (kDoE) solve_E8<double>(p8, Ed);
+      if constexpr (kDoH) solve_H4<double>(p4, Hd);
     }
     {
       double chk_e = 0.0, chk_h = 0.0;
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
-        chk_e = fma(Ed[i], 0.0, chk_e);
-        chk_h = fma(Hd[i], 0.0, chk_h);
+        if constexpr (kDoE) chk_e = fma(Ed[i], 0.0, chk_e);
+        if constexpr (kDoH) chk_h = fma(Hd[i], 0.0, chk_h);
       }
       fin[wave][lane] = (unsigned char)((chk_e == 0.0 ? 1 : 0) | (chk_h == 0.0 ? 2 : 0));
     }
-    double inv = to_unit_f32(Ed, unused, A);
-    {
+    if constexpr (kDoE) {
+      const double inv = to_unit_f32(Ed, unused, A);
       const double R0 = xm * (A[0] + A[1]) + A[2], R1 = xm * (A[3] + A[4]) + A[5], R2 = xm * (A[6] + A[7]) + A[8];
       const double C0 = xm * (A[0] + A[3]) + A[6], C1 = xm * (A[1] + A[4]) + A[7];
       const double Es = (kEpsMfma + 4.0 * kEps32) * (xm * (R0 + R1) + R2);
       const double eL = (kEpsMfma + 2.0 * kEps32) * (R0 + R1 + C0 + C1);
       const double rk = sqrt(two_thr_e2);
       const double G = safety * (Es + rk * eL);
-      ca_own = round_up_f32(4.0 * G * rk * (1.0 + 64.0 * kEps32));
-      cb_own = round_up_f32(4.0 * G * G * (1.0 + 64.0 * kEps32));
+      // float32 evaluation of g = P rsq(P S + tiny): relative error below 8 eps where P S is far above the floor, at most
+      // g <= 1.5e-5 in absolute terms where it is not (then min(n1, n2) < 2e-10); g <= min(L1, L2) <= Lb; the final fma
+      // and the float32 value of sqrt(k) add 2 eps (|s| + sqrt(k) g)
+      const double Lb = fmin(R0 + R1, C0 + C1), Sb = xm * (R0 + R1) + R2;
+      ge_own = all_f64 ? __builtin_inff() : round_up_f32((G + rk * (8.0 * kEps32 * Lb + 1.5e-5) + 2.0 * kEps32 * (Sb + rk * Lb)) * 1.000001);
+#pragma unroll
+      for (int v = 0; v < 3; ++v)
+        pack_pieces(Ed[3 * v] * inv, Ed[3 * v + 1] * inv, Ed[3 * v + 2] * inv, true, bstage[wave][lane][v][0], bstage[wave][lane][v][1]);
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+        pack_pieces(Ed[v] * inv, Ed[3 + v] * inv, Ed[6 + v] * inv, true, bstage[wave][lane][3 + v][0], bstage[wave][lane][3 + v][1]);
     }
-#pragma unroll
-    for (int v = 0; v < 3; ++v)
-      pack_pieces(Ed[3 * v] * inv, Ed[3 * v + 1] * inv, Ed[3 * v + 2] * inv, true, bstage[wave][lane][v][0], bstage[wave][lane][v][1]);
-#pragma unroll
-    for (int v = 0; v < 2; ++v)
-      pack_pieces(Ed[v] * inv, Ed[3 + v] * inv, Ed[6 + v] * inv, true, bstage[wave][lane][3 + v][0], bstage[wave][lane][3 + v][1]);
-    inv = to_unit_f32(Hd, unused, A);
-    {
+    if constexpr (kDoH) {
+      const double inv = to_unit_f32(Hd, unused, A);
       const double R0 = xm * (A[0] + A[1]) + A[2], R1 = xm * (A[3] + A[4]) + A[5], R2 = xm * (A[6] + A[7]) + A[8];
       const double rt = sqrt(thr_h2);
       const double Dx = (kEpsMfma + 3.0 * kEps32) * (R0 + xm * R2), Dy = (kEpsMfma + 3.0 * kEps32) * (R1 + xm * R2);
       const double eq = rt * (kEpsMfma + 2.0 * kEps32) * R2;
       const double e = safety * (Dx + Dy + eq);
-      c1_own = round_up_f32(4.0 * e + 13.0 * kEps32 * rt * R2 * 1.001);
-      c0_own = round_up_f32(4.1 * e * e);
-    }
+      // |dH_c| of a pair that the float32 sign may get wrong is below (4 e + 13 eps Q) |q_c| + 4.1 e^2 with |q_c| <= Q + e, Q = sqrt(T) R2
+      const double Q = rt * R2, c1 = 4.0 * e + 13.0 * kEps32 * Q * 1.001;
+      gh_own = all_f64 ? __builtin_inff() : round_up_f32((c1 * (Q * 1.000001 + e) + 4.1 * e * e) * 1.000001);
 #pragma unroll
-    for (int v = 0; v < 3; ++v)
-      pack_pieces(Hd[3 * v] * inv, Hd[3 * v + 1] * inv, Hd[3 * v + 2] * inv, true, bstage[wave][lane][5 + v][0], bstage[wave][lane][5 + v][1]);
+      for (int v = 0; v < 3; ++v)
+        pack_pieces(Hd[3 * v] * inv, Hd[3 * v + 1] * inv, Hd[3 * v + 2] * inv, true, bstage[wave][lane][kVecE + v][0],
+                    bstage[wave][lane][kVecE + v][1]);
+    }
   }
   __syncthreads();
-  bf16x8 B[2][8];
-  float ca[2], cb[2], c1[2], c0[2];
+  bf16x8 B[2][kVec];
+  float ge[2], gh[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
 #pragma unroll
-    for (int v = 0; v < 8; ++v) B[k][v] = as_bf16x8(bstage[wave][32 * k + col][v][half]);
-    ca[k] = __shfl(ca_own, 32 * k + col);
-    cb[k] = __shfl(cb_own, 32 * k + col);
-    c1[k] = __shfl(c1_own, 32 * k + col);
-    c0[k] = __shfl(c0_own, 32 * k + col);
+    for (int v = 0; v < kVec; ++v) B[k][v] = as_bf16x8(bstage[wave][32 * k + col][v][half]);
+    ge[k] = __shfl(ge_own, 32 * k + col);
+    gh[k] = __shfl(gh_own, 32 * k + col);
   }
   // the piece vectors now live in registers: the wave's part of the staging area is reused for the float64 models (in the
   // solver's own scale) that the re-evaluation of a pair inside a band needs
@@ -685,12 +703,11 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
   double* mstage = reinterpret_cast<double*>(&bstage[wave][0][0][0]);
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
-    mstage[18 * lane + i] = Ed[i];
-    mstage[18 * lane + 9 + i] = Hd[i];
+    if constexpr (kDoE) mstage[kModel * lane + i] = Ed[i];
+    if constexpr (kDoH) mstage[kModel * lane + (kDoE ? 9 : 0) + i] = Hd[i];
   }
   __syncthreads();
-  const float kf = (float)two_thr_e2, rtf = (float)sqrt(thr_h2);
-  const float cc = round_up_f32(28.0 * kEps32 * two_thr_e2);  // float32 rounding of dE near the threshold, doubled
+  const float rkf = (float)sqrt(two_thr_e2), rtf = (float)sqrt(thr_h2);
   const int apos = 16 * ((col >> 2) & 1) + (col & 3) + 4 * (col >> 3);  // see eh_upper_mfma_kernel
   const int ntiles = (n + 31) / 32;
   const int t0 = blockIdx.y * tiles_per_split;
@@ -699,7 +716,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
   const f32x16 zero = {0};
   for (int t = t0; t < t1; ++t) {
     const uint4* src = pieces + 4 * (long long)(t * 32 + apos) + half;
-    const bf16x8 A1 = as_bf16x8(src[0]), A2 = as_bf16x8(src[2]);
+    const bf16x8 A1 = as_bf16x8(src[0]);
     const int nv = min(16, max(0, n - (t * 32 + 16 * half)));
     const unsigned vmask = (0xFFFFu << (16 - nv)) & 0xFFFFu;
     float x2[16], y2[16];
@@ -713,49 +730,70 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      unsigned amb_e, amb_h;
-      {
+      unsigned amb_e = 0, amb_h = 0;
+      if constexpr (kDoE) {
+        const bf16x8 A2 = as_bf16x8(src[2]);
         const f32x16 l0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][0], zero, 0, 0, 0);
         const f32x16 l1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][1], zero, 0, 0, 0);
         const f32x16 l2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][2], zero, 0, 0, 0);
         const f32x16 m0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B[k][3], zero, 0, 0, 0);
         const f32x16 m1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B[k][4], zero, 0, 0, 0);
-        unsigned hneg = 0, hamb = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        auto fE = [&](int i) {  // < 0 <=> inlier
           const float s = fma(l0[i], x2[i], fma(l1[i], y2[i], l2[i]));
           const float n1 = fma(l0[i], l0[i], l1[i] * l1[i]);
           const float n2 = fma(m0[i], m0[i], m1[i] * m1[i]);
           const float S = n1 + n2, P = n1 * n2;
-          const float d = fma(-kf, P, (s * s) * S);  // < 0 <=> inlier
-          hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d), 31);
-          // the constants are inflated so that "inside or on the band" reads "< band"; the floor keeps a degenerate
-          // epipolar line (n1 = n2 = 0 after float32 underflow) inside the band
-          const float band = fma(ca[k], __builtin_amdgcn_sqrtf(P * S), fma(cb[k], S, fma(cc, P, 1.0e-36f)));  // raw v_sqrt_f32: 1 ulp, inside the margin of ca
-          hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(d) - band), 31);  // < 0 <=> the float32 sign is not trusted
-        }
-        amb_e = all_f64 ? vmask : (hamb & vmask);
-        ce[k] += __popc(hneg & vmask & ~amb_e);
-      }
-      {
-        const f32x16 hx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][5], zero, 0, 0, 0);
-        const f32x16 hy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][6], zero, 0, 0, 0);
-        const f32x16 hz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][7], zero, 0, 0, 0);
-        unsigned hneg = 0, hamb = 0;
+          const float g = P * __builtin_amdgcn_rsqf(fma(P, S, 1.0e-36f));  // raw v_rsq_f32: 1 ulp; the floor keeps a degenerate line finite
+          return fma(-rkf, g, fabsf(s));
+        };
+        unsigned hneg = 0;
+        float closest = __builtin_inff();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 16; i += 2) {
+          const float f0 = fE(i), f1 = fE(i + 1);
+          hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(f0), 31);
+          hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(f1), 31);
+          closest = min3_abs(closest, f0, f1);
+        }
+        ce[k] += __popc(hneg & vmask);
+        if (closest <= ge[k]) {  // rare: a pair of this row is too close to the threshold for its float32 sign (or is padding)
+          unsigned hamb = 0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(fE(i)) - ge[k]), 31);
+          amb_e = all_f64 ? vmask : (hamb & vmask);
+          ce[k] -= __popc(hneg & amb_e);  // take the untrusted signs back out
+        }
+      }
+      if constexpr (kDoH) {
+        const f32x16 hx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][kVecE], zero, 0, 0, 0);
+        const f32x16 hy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][kVecE + 1], zero, 0, 0, 0);
+        const f32x16 hz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][kVecE + 2], zero, 0, 0, 0);
+        auto dH = [&](int i) {  // < 0 <=> inlier
           const float dx = fma(x2[i], hz[i], -hx[i]);
           const float dy = fma(y2[i], hz[i], -hy[i]);
           const float q = rtf * hz[i];
-          const float d = fma(-q, q, fma(dy, dy, dx * dx));
-          hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d), 31);
-          hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(d) - fma(c1[k], fabsf(q), c0[k])), 31);
+          return fma(-q, q, fma(dy, dy, dx * dx));
+        };
+        unsigned hneg = 0;
+        float closest = __builtin_inff();
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          const float d0 = dH(i), d1 = dH(i + 1);
+          hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d0), 31);
+          hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d1), 31);
+          closest = min3_abs(closest, d0, d1);
         }
-        amb_h = all_f64 ? vmask : (hamb & vmask);
-        ch[k] += __popc(hneg & vmask & ~amb_h);
+        ch[k] += __popc(hneg & vmask);
+        if (closest <= gh[k]) {
+          unsigned hamb = 0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(dH(i)) - gh[k]), 31);
+          amb_h = all_f64 ? vmask : (hamb & vmask);
+          ch[k] -= __popc(hneg & amb_h);
+        }
       }
       if (amb_e | amb_h) {
-        const double* M = mstage + 18 * (32 * k + col);
+        const double* M = mstage + kModel * (32 * k + col);
         if (amb_e) {
           double E[9];
 #pragma unroll
@@ -770,7 +808,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
         if (amb_h) {
           double H[9];
 #pragma unroll
-          for (int i = 0; i < 9; ++i) H[i] = M[9 + i];
+          for (int i = 0; i < 9; ++i) H[i] = M[(kDoE ? 9 : 0) + i];
           while (amb_h) {
             const int b = __ffs((int)amb_h) - 1;
             amb_h &= amb_h - 1;
@@ -791,11 +829,11 @@ __global__ __launch_bounds__(kBlock, 2) void eh_score_mfma_kernel(const double4*
   const int oute = (ok & 1u) ? (half ? se[1] : se[0]) : 0, outh = (ok & 2u) ? (half ? sh[1] : sh[0]) : 0;
   if (gid < nb) {
     if (use_atomics) {
-      atomicAdd(count_e + gid, oute);
-      atomicAdd(count_h + gid, outh);
+      if constexpr (kDoE) atomicAdd(count_e + gid, oute);
+      if constexpr (kDoH) atomicAdd(count_h + gid, outh);
     } else {
-      count_e[gid] = oute;
-      count_h[gid] = outh;
+      if constexpr (kDoE) count_e[gid] = oute;
+      if constexpr (kDoH) count_h[gid] = outh;
     }
   }
 }
@@ -1315,13 +1353,6 @@ __global__ __launch_bounds__(kBlock) void t_upper_kernel(const double* __restric
 // 16 pairs.  Pairs inside the band (about one in 10^6) are then found and re-evaluated with the float64 test of
 // t_score_kernel on the spot, so the counts are identical to t_score_kernel's for every hypothesis.
 // ---------------------------------------------------------------------------------------
-// min(m, |a|, |b|) in one instruction (m >= 0); a NaN operand is ignored, as by fminf
-__device__ __forceinline__ float min3_abs(float m, float a, float b) {
-  float r;
-  asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
-  return r;
-}
-
 struct CamPad {
   int64_t poff[kMaxCams + 1];  // offsets of the cameras in the padded (multiple of 32) point numbering
 };
@@ -2061,8 +2092,18 @@ static int run_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx,
   SFM_TRY(hipMemsetAsync(xy + npad, 0, 16, st));  // trailer: measured max |coordinate|
   corr_to_mfma2_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, pieces, xy);
   SFM_TRY(check_launch());
-  eh_score_mfma_kernel<<<dim3((unsigned)tiles, splits), kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e,
-                                                                        thr_h * thr_h, xmax, count_e, count_h, tps, splits > 1);
+  static const int split_models = getenv("SFM_HIP_EHX_SPLIT") ? atoi(getenv("SFM_HIP_EHX_SPLIT")) : 0;
+  const dim3 grid((unsigned)tiles, splits);
+  if (split_models) {
+    eh_score_mfma_kernel<true, false, 3><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e, thr_h * thr_h,
+                                                                 xmax, count_e, count_h, tps, splits > 1);
+    SFM_TRY(check_launch());
+    eh_score_mfma_kernel<false, true, 4><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e, thr_h * thr_h,
+                                                                 xmax, count_e, count_h, tps, splits > 1);
+  } else {
+    eh_score_mfma_kernel<true, true, 2><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e, thr_h * thr_h,
+                                                                xmax, count_e, count_h, tps, splits > 1);
+  }
   return check_launch();
 }
 
