@@ -128,33 +128,62 @@ def replay_block(st, idx, cE, cH, backend, exact=None):
     return j
 
 
+def _block_size(it, lim, chunk, max_iterations):
+    """Size of the next block for a loop that stands at iteration `it` with trip count `lim` (0: nothing left to draw)."""
+    if not it < lim:
+        return 0
+    nb = chunk if not np.isfinite(lim) else int(min(chunk, max(1, math.ceil(lim - it))))
+    if max_iterations is not None:
+        nb = min(nb, max_iterations - it)
+    return max(nb, 0)
+
+
+def _draw(n, nb):
+    """(stream position before the draw, index sets): == np.random.randint(0, n, size=12 * nb), same stream position after."""
+    mark = legacy_rng.mark()
+    return mark, legacy_rng.randint(n, 12 * nb).reshape(nb, 12)
+
+
 def run_replay(n, backend, chunk0=4096, chunk_max=1 << 18, max_iterations=None):
     """Draws index blocks from np.random, scores them through `backend` and replays the state
-    machine; rewinds the stream so that exactly 12 integers per executed iteration are consumed."""
+    machine; rewinds the stream so that exactly 12 integers per executed iteration are consumed.
+
+    A backend with submit/collect scores a block asynchronously: the next block's index sets are drawn on the host
+    while the GPU works (sized as if the block in flight ran to its end; a loop that ends earlier just leaves more
+    to rewind)."""
     st = ReplayState(n)
     chunk = chunk0
-    while st.it < st.limit():
-        if max_iterations is not None and st.it >= max_iterations:
-            break
-        lim = st.limit()
-        nb = chunk if not np.isfinite(lim) else int(min(chunk, max(1, math.ceil(lim - st.it))))
-        if max_iterations is not None:
-            nb = max(1, min(nb, max_iterations - st.it))
-        rng_state = legacy_rng.mark()
-        idx = legacy_rng.randint(n, 12 * nb).reshape(nb, 12)  # == np.random.randint(0, n, size=12 * nb), same stream position after
-        exact = None
-        bounded = backend.score_bounded(idx, st.best_E, st.best_H) if hasattr(backend, "score_bounded") else None
-        if bounded is not None:
-            cE, cH, exact = bounded
-        else:
-            cE, cH = backend.score(idx)
-        used = replay_block(st, idx, cE, cH, backend, exact)
-        if used < nb:
-            legacy_rng.rewind(rng_state)
-            if used > 0:
-                legacy_rng.randint(n, 12 * used)
-            break
+    nb = _block_size(st.it, st.limit(), chunk, max_iterations)
+    nxt = _draw(n, nb) if nb else None
+    while nxt is not None:
+        rng_state, idx = nxt
+        nb = idx.shape[0]
+        handle = backend.submit(idx, st.best_E, st.best_H) if hasattr(backend, "submit") else None
         chunk = min(chunk * 2, chunk_max)
+        nb_ahead = _block_size(st.it + nb, st.limit(), chunk, max_iterations)
+        nxt = _draw(n, nb_ahead) if nb_ahead else None  # speculative: overlaps with the scoring of this block
+        exact = None
+        if handle is not None:
+            cE, cH, exact = backend.collect(handle, st.best_E, st.best_H)
+        else:
+            bounded = backend.score_bounded(idx, st.best_E, st.best_H) if hasattr(backend, "score_bounded") else None
+            if bounded is not None:
+                cE, cH, exact = bounded
+            else:
+                cE, cH = backend.score(idx)
+        used = replay_block(st, idx, cE, cH, backend, exact)
+        ended = used < nb or not st.it < st.limit() or (max_iterations is not None and st.it >= max_iterations)
+        if ended:
+            if used == nb and nxt is not None:
+                legacy_rng.rewind(nxt[0])  # takes back the block drawn ahead
+            elif used < nb:
+                legacy_rng.rewind(rng_state)  # also takes back the block drawn ahead
+                if used > 0:
+                    legacy_rng.randint(n, 12 * used)
+            break
+        if nxt is None:  # the trip count grew past what was planned (an accepted H record may lower the best E count)
+            nb = _block_size(st.it, st.limit(), chunk, max_iterations)
+            nxt = _draw(n, nb) if nb else None
     if st.pending_E is not None:
         st.R, st.T, st.inliers = backend.e_record(st.pending_E)
         st.pending_E = None
@@ -183,24 +212,32 @@ class GpuBackend:
     MAX_PREFETCH = 64
     BOUNDED_MIN_PAIRS = 1 << 28  # below this a block is scored exactly: the launch, not the arithmetic, is what costs
 
-    def score_bounded(self, idx, best_E, best_H):
-        """Block scoring driven by bounds (large blocks only): matrix-core UPPER bounds for every hypothesis, exact
-        float64 counts only for those whose bound exceeds a running best (the only ones the loop can ever look at).
-        Returns (cE, cH, exact) or None when exact scoring of the whole block is the better choice."""
-        import torch
-
+    def submit(self, idx, best_E, best_H):
+        """Uploads a block and launches its scoring without waiting for it: matrix-core UPPER bounds when the block is
+        large and both running bests exist (the loop only ever looks at hypotheses whose counts exceed them), otherwise
+        the exact counts of every hypothesis."""
         nb = idx.shape[0]
-        if nb * self.n < self.BOUNDED_MIN_PAIRS or best_E <= 0 or best_H <= 0:
-            return None
         d_idx = C.dev(idx, np.int32)
+        if nb * self.n < self.BOUNDED_MIN_PAIRS or best_E <= 0 or best_H <= 0:
+            return ("exact", d_idx) + ops.eh_score_mixed(self.corr, d_idx, self.thr, 3 * self.thr)
         if getattr(self, "corrm", None) is None:
             self.corrm = ops.corr_to_mfma(self.corr, self.thr)
-        ue, uh = ops.eh_upper_mfma(self.corr, self.corrm, d_idx, self.thr, 3 * self.thr)
-        cand = torch.nonzero((ue > best_E) | (uh > best_H)).flatten()
-        if cand.shape[0] > nb // 8:
-            return None  # the bests are still low: nearly everything is a candidate
+        return ("bounds", d_idx) + ops.eh_upper_mfma(self.corr, self.corrm, d_idx, self.thr, 3 * self.thr)
+
+    def collect(self, handle, best_E, best_H):
+        """(cE, cH, exact) of a submitted block; exact is None when every count is exact, else a mask (see replay_block)."""
+        import torch
+
+        kind, d_idx, ue, uh = handle
         self.d_idx = d_idx
         self.h_cache = {}
+        if kind == "exact":
+            return ue.cpu().numpy(), uh.cpu().numpy(), None
+        nb = d_idx.shape[0]
+        cand = torch.nonzero((ue > best_E) | (uh > best_H)).flatten()
+        if cand.shape[0] > nb // 8:  # the bests are still low, nearly everything is a candidate: exact counts for the whole block
+            ce, ch = ops.eh_score_mixed(self.corr, d_idx, self.thr, 3 * self.thr)
+            return ce.cpu().numpy(), ch.cpu().numpy(), None
         exact = np.zeros(nb, bool)
         if cand.shape[0]:
             xe, xh = ops.eh_score(self.corr, d_idx.index_select(0, cand), self.thr, 3 * self.thr)
@@ -208,6 +245,14 @@ class GpuBackend:
             uh[cand] = xh
             exact[cand.cpu().numpy()] = True
         return ue.cpu().numpy(), uh.cpu().numpy(), exact
+
+    def score_bounded(self, idx, best_E, best_H):
+        """Synchronous form of submit + collect for large blocks; None when exact scoring of the whole block is the
+        better choice (small block, or no running bests yet)."""
+        if idx.shape[0] * self.n < self.BOUNDED_MIN_PAIRS or best_E <= 0 or best_H <= 0:
+            return None
+        cE, cH, exact = self.collect(self.submit(idx, best_E, best_H), best_E, best_H)
+        return (cE, cH, exact) if exact is not None else (cE, cH, np.ones(idx.shape[0], bool))
 
     def refine(self, positions):
         """Exact counts of the given positions of the block scored last."""

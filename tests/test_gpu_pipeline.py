@@ -45,15 +45,15 @@ def test_run_ransac_bound_driven_blocks_match_reference(sfm, golden, tag, monkey
     from sfm_hip import ransac_algorithm as ra
 
     used = []
-    orig = ra.GpuBackend.score_bounded
+    orig = ra.GpuBackend.submit
 
     def spy(self, idx, bE, bH):
         out = orig(self, idx, bE, bH)
-        used.append(out is not None)
+        used.append(out[0] == "bounds")
         return out
 
     monkeypatch.setattr(ra.GpuBackend, "BOUNDED_MIN_PAIRS", 0)
-    monkeypatch.setattr(ra.GpuBackend, "score_bounded", spy)
+    monkeypatch.setattr(ra.GpuBackend, "submit", spy)
     g = golden("eh_ransac.npz")
     sc = two_view(g[f"{tag}_scene"])
     np.random.seed(int(g[f"{tag}_seed"]))

@@ -139,6 +139,53 @@ def test_bound_driven_replay_reproduces_reference_runs(golden, tag, chunk0):
     np.testing.assert_array_equal(np.random.randint(0, 2**31 - 1, size=4), g[f"{tag}_next_draws"])
 
 
+class AsyncOracleBackend(BoundedOracleBackend):
+    """The submit / collect form the GPU backend offers: run_replay draws the next block while this one is 'in flight'
+    and must still leave the stream exactly where the reference leaves it."""
+
+    def submit(self, idx, best_E, best_H):
+        self.submitted = getattr(self, "submitted", 0) + 1
+        return (idx, best_E > 0 and best_H > 0)
+
+    def collect(self, handle, best_E, best_H):
+        idx, bounded = handle
+        if bounded:
+            return self.score_bounded(idx, best_E, best_H)
+        return self.score(idx) + (None,)
+
+
+@pytest.mark.parametrize("tag,chunk0,chunk_max", [("a", 64, 1 << 18), ("b", 16, 64), ("c", 5, 1 << 18), ("c", 32, 32), ("a", 100000, 100000)])
+def test_draw_ahead_replay_reproduces_reference_runs(golden, tag, chunk0, chunk_max):
+    g = golden("eh_ransac.npz")
+    n, inl, pl, seed = g[f"{tag}_scene"]
+    sc = synthetic.two_view_scene(n=int(n), inlier_ratio=float(inl), planar_ratio=float(pl), seed=int(seed))
+    x1 = orc.normalize_K(sc["K"], sc["x1"])
+    x2 = orc.normalize_K(sc["K"], sc["x2"])
+    np.random.seed(int(g[f"{tag}_seed"]))
+    be = AsyncOracleBackend(x1, x2, 1.0 / sc["K"][0][0])
+    st = run_replay(int(n), be, chunk0=chunk0, chunk_max=chunk_max)
+    assert be.submitted > 0
+    assert st.it == len(g[f"{tag}_cH"])
+    np.testing.assert_allclose(st.R, g[f"{tag}_R"], atol=1e-9)
+    np.testing.assert_allclose(np.reshape(st.T, (3, 1)), g[f"{tag}_T"], atol=1e-9)
+    np.testing.assert_array_equal(np.packbits(st.inliers), g[f"{tag}_inliers"])
+    np.testing.assert_array_equal(np.random.randint(0, 2**31 - 1, size=4), g[f"{tag}_next_draws"])
+
+
+def test_draw_ahead_replay_honours_an_iteration_cap():
+    sc = synthetic.two_view_scene(n=400, inlier_ratio=0.2, planar_ratio=0.5, seed=2)
+    x1 = orc.normalize_K(sc["K"], sc["x1"])
+    x2 = orc.normalize_K(sc["K"], sc["x2"])
+    for cap in (1, 63, 64, 65, 200):
+        np.random.seed(9)
+        st = run_replay(400, AsyncOracleBackend(x1, x2, 1.0 / sc["K"][0][0]), chunk0=64, max_iterations=cap)
+        after = np.random.randint(0, 1 << 30, 2)
+        np.random.seed(9)
+        np.random.randint(0, 400, size=12 * st.it)
+        np.testing.assert_array_equal(after, np.random.randint(0, 1 << 30, 2))
+        assert st.it <= cap
+
+
 def test_bound_driven_replay_refines_after_the_best_E_count_was_lowered():
     """An accepted H record may LOWER the best E count (the reference compares with the current iteration's E count);
     bounds that were filtered against the old best must then be replaced by exact counts before the loop reads them."""
