@@ -420,6 +420,13 @@ __global__ __launch_bounds__(kBlock) void corr_to_mfma_kernel(const double4* __r
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
+// Sign histories of the MFMA kernels hold 16 matches per lane half (bit 15-i = match 16*half + i of a tile of 32); the
+// only tile with padding is tile n/32 when n is not a multiple of 32: this is its mask of real matches.
+__device__ __forceinline__ unsigned tile_tail_mask(int n, int half) {
+  const int nv = min(16, max(0, (n & 31) - 16 * half));
+  return (0xFFFFu << (16 - nv)) & 0xFFFFu;
+}
+
 // min(m, |a|, |b|) in one instruction (m >= 0); a NaN operand is ignored, as by fminf
 __device__ __forceinline__ float min3_abs(float m, float a, float b) {
   float r;
@@ -511,14 +518,16 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
   int ce[2] = {0, 0}, ch[2] = {0, 0};
   unsigned he[2] = {0, 0}, hh[2] = {0, 0};  // sign-bit histories: one v_alignbit per test instead of compare + add-with-carry
   const f32x16 zero = {0};
-  for (int t = t0; t < t1; ++t) {
-    const bf16x8 A = as_bf16x8(pieces[2 * (t * 32 + apos) + half]);
-    // bit 15-i of a history is match 16*half + i of this tile; the padding of the last tile is masked out
-    const int nv = min(16, max(0, n - (t * 32 + 16 * half)));
-    const unsigned vmask = (0xFFFFu << (16 - nv)) & 0xFFFFu;
+  // bit 15-i of a history is match 16*half + i of a tile; only tile n/32 (when n is not a multiple of 32) has padding to mask out
+  const unsigned tail_mask = tile_tail_mask(n, half);
+  const uint4* asrc = pieces + 2 * (t0 * 32 + apos) + half;
+  const float4* xsrc = reinterpret_cast<const float4*>(xy + t0 * 32 + 16 * half);
+  for (int t = t0; t < t1; ++t, asrc += 64, xsrc += 16) {
+    const bf16x8 A = as_bf16x8(*asrc);
+    const unsigned vmask = t == (n >> 5) ? tail_mask : 0xFFFFu;
     float x2[16], y2[16];
     {
-      const float4* q = reinterpret_cast<const float4*>(xy + t * 32 + 16 * half);
+      const float4* q = xsrc;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float4 v = q[i];
@@ -714,14 +723,15 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma_kernel(const
   const int t1 = min(ntiles, t0 + tiles_per_split);
   int ce[2] = {0, 0}, ch[2] = {0, 0};
   const f32x16 zero = {0};
-  for (int t = t0; t < t1; ++t) {
-    const uint4* src = pieces + 4 * (long long)(t * 32 + apos) + half;
+  const unsigned tail_mask = tile_tail_mask(n, half);
+  const uint4* src = pieces + 4 * (long long)(t0 * 32 + apos) + half;
+  const float4* xsrc = reinterpret_cast<const float4*>(xy + t0 * 32 + 16 * half);
+  for (int t = t0; t < t1; ++t, src += 128, xsrc += 16) {
     const bf16x8 A1 = as_bf16x8(src[0]);
-    const int nv = min(16, max(0, n - (t * 32 + 16 * half)));
-    const unsigned vmask = (0xFFFFu << (16 - nv)) & 0xFFFFu;
+    const unsigned vmask = t == (n >> 5) ? tail_mask : 0xFFFFu;
     float x2[16], y2[16];
     {
-      const float4* q = reinterpret_cast<const float4*>(xy + t * 32 + 16 * half);
+      const float4* q = xsrc;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float4 v = q[i];
@@ -1501,11 +1511,11 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
   const int t1 = min(ntiles, t0 + tiles_per_split);
   int cnt[2] = {0, 0};
   const f32x16 zero = {0};
-  for (int t = t0; t < t1; ++t) {
-    const uint4* src = pc + 6 * (t * 32 + apos) + half;
+  const unsigned tail_mask = tile_tail_mask(m, half);
+  const uint4* src = pc + 6 * (t0 * 32 + apos) + half;
+  for (int t = t0; t < t1; ++t, src += 192) {
     const bf16x8 Ax = as_bf16x8(src[0]), Ay = as_bf16x8(src[2]), Aq = as_bf16x8(src[4]);
-    const int nv = min(16, max(0, m - (t * 32 + 16 * half)));
-    const unsigned vmask = (0xFFFFu << (16 - nv)) & 0xFFFFu;
+    const unsigned vmask = t == (m >> 5) ? tail_mask : 0xFFFFu;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const f32x16 dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ax, B[k][0], zero, 0, 0, 0);
