@@ -169,3 +169,39 @@ def test_models_do_not_depend_on_wave_neighbours(env):
         Ea, Ha = alone[0].cpu().numpy(), alone[1].cpu().numpy()
         assert np.array_equal(Ea[0], Em[r], equal_nan=True) and np.array_equal(Ha[0], Hm[r], equal_nan=True)
         assert np.array_equal(Ea[0], Ea[63], equal_nan=True)
+
+
+def test_large_but_finite_coordinates_keep_exact_counts(env):
+    """Coordinates far outside the normalised range: pixel-sized values (float32 error bands grow with them), one match at
+    3e5 (bounds still usable, the exact scorer already routes every pair to float64) and a translation problem whose
+    points are so large that float32 squares would overflow.  Every mixed-precision count must equal the float64 count."""
+    torch, C, ops = env
+    n, B = 900, 4000
+    sc, x1, x2 = scene(n, seed=11)
+    idx = C.dev(np.random.default_rng(4).integers(0, n, (B, 12)), np.int32)
+    for scale, poison, thr in ((1.0, 3.0e5, 1.0 / sc["K"][0][0]), (sc["K"][0][0], None, 1.0), (37.5, None, 37.5 / sc["K"][0][0])):
+        corr_h = ops.pack_corr(x1, x2)
+        corr_h *= scale
+        if poison is not None:
+            corr_h[55, 1] = poison
+        corr = C.dev(corr_h)
+        c32 = ops.corr_to_f32(corr)
+        ce, ch = ops.eh_score(corr, idx, thr, 3 * thr)
+        me, mh = ops.eh_score_mixed(corr, idx, thr, 3 * thr)
+        assert torch.equal(me, ce) and torch.equal(mh, ch)
+        ue, uh = ops.eh_upper_mfma(corr, ops.corr_to_mfma(corr, thr), idx, thr, 3 * thr, 0.0)
+        assert bool((ue >= ce).all()) and bool((uh >= ch).all())
+        ce_h, ch_h = ce.cpu().numpy(), ch.cpu().numpy()
+        wE, wH, _ = ops.eh_best_native(corr, c32, idx, thr, 3 * thr, 0.0)
+        assert wE == (int(ce_h.max()), int(np.argmax(ce_h))) and wH == (int(ch_h.max()), int(np.argmax(ch_h)))
+    # translation stage: one camera with ordinary points, one with a point at 1e20, one scaled by 1e9
+    cams = [synthetic.resection_scene(m=500, outlier_ratio=0.4, seed=20 + i) for i in range(3)]
+    cams[1]["X"] = cams[1]["X"].copy()
+    cams[1]["X"][:, 7] = 1.0e20
+    cams[2]["X"] = cams[2]["X"] * np.float32(1.0e9)
+    pts = torch.cat([ops.pack_points(C.dev(c["R"].ravel()), C.dev(c["X"]), C.dev(c["x_norm"])) for c in cams])
+    idx_t = C.dev(np.random.default_rng(5).integers(0, 500, (3, 3000, 2)), np.int32)
+    thr_t = 4.0 / synthetic.K_DATASET5[0][0]
+    b64, _, c64 = ops.t_ransac(pts, [500] * 3, idx_t, thr_t, mixed=False)
+    bmx, _, cmx = ops.t_ransac(pts, [500] * 3, idx_t, thr_t, mixed=True)
+    assert torch.equal(c64, cmx) and torch.equal(b64, bmx)
