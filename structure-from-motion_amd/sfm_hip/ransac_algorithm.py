@@ -101,6 +101,10 @@ def replay_block(st, idx, cE, cH, backend, exact=None):
         nE = int(cE[j])
         if nE > st.best_E:  # :105-113
             st.best_E = nE
+            if len(set(idx[j][:S_E].tolist())) < S_E:
+                # a sample drawn with a repeated match makes the 8-point system rank deficient: its null vector is an
+                # arbitrary one, here as in LAPACK, so this record need not coincide with the reference's
+                logging.info("E record at iteration %d comes from a sample with a repeated match", st.it)
             # R, T and the inlier mask of an E record are only ever read after the loop, and any later record
             # overwrites them: the O(N) work (essential_to_RT over all matches, :110) is done once, for the last one
             st.pending_E = np.array(idx[j])
@@ -109,6 +113,8 @@ def replay_block(st, idx, cE, cH, backend, exact=None):
         nH = int(cH[j])
         if nH > st.best_H:  # :124-169
             st.best_H = nH
+            if len(set(idx[j][S_E:].tolist())) < S_H:
+                logging.info("H record at iteration %d comes from a sample with a repeated match", st.it)
             (Ra, Ta, na, ma), (Rb, Tb, nb_, mb) = backend.h_record(idx[j])
             pick = None
             if na > nb_:
