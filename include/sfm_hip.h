@@ -33,6 +33,7 @@
 #ifndef SFM_HIP_H
 #define SFM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -312,6 +313,31 @@ int64_t sfm_knn2_workspace_bytes(int32_t nq, int32_t nt);
 int sfm_knn2_ratio_i8(const int8_t* q8, const int32_t* qnorm, int32_t nq, const int8_t* t8, const int32_t* tnorm, int32_t nt,
                       double ratio, void* workspace, int64_t workspace_bytes, int32_t* train_idx, float* dist1, float* dist2,
                       uint8_t* good, int32_t* good_count, void* stream);
+
+/* ---- SIFT detection and description (feature front-end next to the path) ---------------------
+ * Replaces `cv2.SIFT_create().detectAndCompute(gray, None)` (src/extract_sift.py:104-114, src/utils.py:78-80): Lowe's
+ * SIFT with OpenCV's default parameters (doubled base image, 3 layers per octave, sigma 1.6, contrast threshold 0.04,
+ * edge threshold 10, descriptors 128 integers in [0, 255]).  OpenCV is not part of the reference's tree: results are
+ * checked against a restatement of the published algorithm, not against cv2 itself.
+ *
+ * sfm_sift_workspace_bytes: device bytes for an image of w x h pixels (0 when the size is not supported).
+ * sfm_sift_detect: gray uint8[h][w] (device).  Builds the scale space in the workspace and writes the oriented
+ *   keypoints, in no particular order and BEFORE duplicate removal, as keypoints float32[capacity][6] =
+ *   (x, y, size, angle in degrees, response, packed octave as integer bits; x, y, size in pixels of the DOUBLED
+ *   image, as OpenCV holds them at that stage).  *count (host) = number found; SFM_ETOOLARGE when it exceeds capacity
+ *   (the first `capacity` are valid).  Synchronises the stream.
+ * sfm_sift_describe: descriptors uint8[n][128] for n final keypoints (device float32[n][6], coordinates of the input
+ *   image, octave field repacked for firstOctave = -1, i.e. what OpenCV's KeyPoint holds after detection), from the
+ *   scale space a preceding sfm_sift_detect of the same image left in the workspace.
+ * sfm_sift_gaussian_taps (host only): the float32 taps of the blur for one sigma (ksize <= 64), for tests.
+ * sfm_sift_octaves (host only): number of octaves and, per octave, width, height and the offset (in floats) of its
+ *   six Gaussian images in the workspace. */
+size_t sfm_sift_workspace_bytes(int32_t w, int32_t h);
+int sfm_sift_detect(const uint8_t* gray, int32_t w, int32_t h, void* workspace, size_t workspace_bytes, float* keypoints, int32_t capacity,
+                    int32_t* count, void* stream);
+int sfm_sift_describe(const void* workspace, int32_t w, int32_t h, const float* keypoints, int32_t n, uint8_t* descriptors, void* stream);
+int sfm_sift_gaussian_taps(double sigma, float* taps, int32_t* ksize);
+int sfm_sift_octaves(int32_t w, int32_t h, int32_t* noct, int32_t* widths, int32_t* heights, int64_t* gauss_offsets);
 
 #ifdef __cplusplus
 }

@@ -68,6 +68,11 @@ _SIGS = {
     "sfm_descriptors_to_i8": (_c.c_int, [_P, _c.c_int32, _c.c_int64, _P, _P, _P, _P]),
     "sfm_knn2_workspace_bytes": (_c.c_int64, [_c.c_int32, _c.c_int32]),
     "sfm_knn2_ratio_i8": (_c.c_int, [_P, _P, _c.c_int32, _P, _P, _c.c_int32, _c.c_double, _P, _c.c_int64, _P, _P, _P, _P, _P, _P]),
+    "sfm_sift_workspace_bytes": (_c.c_size_t, [_c.c_int32, _c.c_int32]),
+    "sfm_sift_detect": (_c.c_int, [_P, _c.c_int32, _c.c_int32, _P, _c.c_size_t, _P, _c.c_int32, _P, _P]),
+    "sfm_sift_describe": (_c.c_int, [_P, _c.c_int32, _c.c_int32, _P, _c.c_int32, _P, _P]),
+    "sfm_sift_gaussian_taps": (_c.c_int, [_c.c_double, _P, _P]),
+    "sfm_sift_octaves": (_c.c_int, [_c.c_int32, _c.c_int32, _P, _P, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["sfm_hip_error_string"])

@@ -1,7 +1,7 @@
 """Descriptor matching on the GPU for the feature front-end (src/extract_sift.py:117-123, src/utils.py:82-86).
 
 The reference matches with ``cv2.BFMatcher().knnMatch(query, train, k=2)`` and a ratio test.  Here the 2-NN search runs
-on the int8 matrix cores (exact integer squared distances) and only SIFT detection itself still needs OpenCV.
+on the int8 matrix cores (exact integer squared distances); SIFT detection runs on the GPU as well (sfm_hip/sift.py).
 Features of an image are kept per (path, read mode) so that SIFT runs once per image instead of once per call: the
 reference detects every image again in estimate_translation and in refine_translation.
 """
@@ -51,7 +51,7 @@ def knn_match_ratio(desc_query, desc_train, ratio):
 def image_features(img_path, mode):
     """SIFT keypoints (float32 [n][2]) and descriptors (uint8 [n][128]) of one image, detected once per (path, mode).
     mode "bgr2gray": cv2.imread + cvtColor (src/extract_sift.py:104-114); mode "grayscale": cv2.imread(IMREAD_GRAYSCALE)
-    (src/utils.py:78-80).  Needs OpenCV unless the features are cached."""
+    (src/utils.py:78-80)."""
     key = (os.path.abspath(img_path), mode)
     if key in _features:
         return _features[key]
@@ -62,24 +62,28 @@ def image_features(img_path, mode):
             with np.load(cache) as z:
                 _features[key] = (z["keypoints"], z["descriptors"])
             return _features[key]
-    try:
-        import cv2
-    except ImportError as e:  # pragma: no cover - depends on the machine
-        raise ImportError("SIFT detection needs OpenCV (cv2); provide cached features or precomputed correspondences") from e
-    if mode == "bgr2gray":
-        gray = cv2.cvtColor(cv2.imread(img_path), cv2.COLOR_BGR2GRAY)
-    elif mode == "grayscale":
-        gray = cv2.imread(img_path, cv2.IMREAD_GRAYSCALE)
-    else:
-        raise ValueError(mode)
-    kps, desc = cv2.SIFT_create().detectAndCompute(gray, None)
-    kp = np.float32([k.pt for k in kps]).reshape(-1, 2)
-    feats = (kp, np.ascontiguousarray(desc).astype(np.uint8) if desc is not None else np.zeros((0, 128), np.uint8))
+    feats = detect_features(img_path, mode)
     _features[key] = feats
     if cache:
         os.makedirs(FEATURE_CACHE_DIR, exist_ok=True)
         np.savez(cache, keypoints=feats[0], descriptors=feats[1])
     return feats
+
+
+def detect_features(img_path, mode):
+    """SIFT of one image on the GPU (sfm_hip/sift.py).  SFM_HIP_SIFT=cv2 runs OpenCV's detector instead, for users who
+    have it installed and want the reference's features bit for bit."""
+    from . import sift
+
+    gray = sift.read_gray(img_path, mode)
+    if os.environ.get("SFM_HIP_SIFT", "hip") == "cv2":
+        import cv2
+
+        kps, desc = cv2.SIFT_create().detectAndCompute(gray, None)
+        kp = np.float32([k.pt for k in kps]).reshape(-1, 2)
+        return kp, (np.ascontiguousarray(desc).astype(np.uint8) if desc is not None else np.zeros((0, 128), np.uint8))
+    res = sift.detect_and_compute(gray)
+    return res.keypoints, res.descriptors
 
 
 def match_keypoints(kp1, desc1, kp2, desc2, ratio=0.4):

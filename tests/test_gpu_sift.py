@@ -1,0 +1,110 @@
+"""GPU SIFT (csrc/sfm_sift.hip) against the NumPy restatement of the algorithm (oracle/sift.py) on synthetic images:
+the scale space and the detection stage bit for bit, orientations and descriptors within the stated float32 tolerances
+(expf / powf / cosf differ in the last place between the device and NumPy).  Parity with cv2 itself is unpinned:
+OpenCV is not installed and the reference holds no keypoint fixtures."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import sift as osift
+
+pytestmark = pytest.mark.gpu
+
+
+def blob_image(h, w, n_blobs, seed):
+    rng = np.random.default_rng(seed)
+    img = np.zeros((h, w))
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(n_blobs):
+        cx, cy, s, a = rng.uniform(8, w - 8), rng.uniform(8, h - 8), rng.uniform(1.2, 7), rng.uniform(-1, 1)
+        e = rng.uniform(0.6, 1.6)
+        img += a * np.exp(-(((xx - cx) / e) ** 2 + ((yy - cy) * e) ** 2) / (2 * s * s))
+    img += rng.normal(0, 0.01, img.shape)
+    return (255 * (img - img.min()) / (img.max() - img.min())).astype(np.uint8)
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    from sfm_hip import _capi, sift
+
+    _capi.load_library()
+    return torch, _capi, sift
+
+
+@pytest.mark.parametrize("h,w,seed", [(120, 160, 0), (97, 131, 1), (64, 200, 2)])
+def test_scale_space_and_keypoints_equal_the_restatement(env, h, w, seed):
+    torch, C, sift = env
+    lib = C.load_library()
+    img = blob_image(h, w, 70, seed)
+    # taps: the library's own (float32 values of a double exp; NumPy's exp may differ in the last place of the double)
+    for sigma in [1.2489995996796797] + osift.layer_sigmas()[1:]:
+        np.testing.assert_allclose(sift.gaussian_taps(sigma), osift.gaussian_taps(sigma), rtol=2e-7, atol=0)
+    kps_o, (gauss_o, dog_o) = osift.detect(img, taps_fn=sift.gaussian_taps)
+    desc_o = osift.describe(kps_o, gauss_o)
+
+    # run the library by hand to look at the workspace
+    g = torch.from_numpy(img).cuda()
+    nbytes = int(lib.sfm_sift_workspace_bytes(w, h))
+    ws = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+    cap = 1 << 15
+    kps = torch.empty((cap, 6), dtype=torch.float32, device="cuda")
+    count = ctypes.c_int32(0)
+    C.check(lib.sfm_sift_detect(C.dptr(g), w, h, C.dptr(ws), nbytes, C.dptr(kps), cap, ctypes.byref(count), C.stream_ptr()))
+    noct = ctypes.c_int32(0)
+    W = np.zeros(16, np.int32)
+    H = np.zeros(16, np.int32)
+    off = np.zeros(16, np.int64)
+    C.check(lib.sfm_sift_octaves(w, h, ctypes.byref(noct), C.hptr(W), C.hptr(H), C.hptr(off)))
+    assert noct.value == len(gauss_o)
+    ws_h = ws.cpu().numpy()
+    for o in range(noct.value):
+        assert (H[o], W[o]) == gauss_o[o][0].shape
+        planes = ws_h[off[o] : off[o] + 6 * W[o] * H[o]].reshape(6, H[o], W[o])
+        for i in range(6):
+            np.testing.assert_array_equal(planes[i], gauss_o[o][i], err_msg=f"octave {o} layer {i}")  # bit for bit
+
+    res = sift.detect_and_compute(img)
+    assert res.records.shape[0] == len(kps_o) > 15
+    ko = np.array([k[:5] for k in kps_o], np.float64)
+    kg = res.records[:, :5].astype(np.float64)
+    np.testing.assert_array_equal(kg[:, :2], ko[:, :2])  # positions: detection is float32 arithmetic only
+    np.testing.assert_allclose(kg[:, 2], ko[:, 2], rtol=1e-6)  # size goes through powf
+    np.testing.assert_allclose(kg[:, 4], ko[:, 4], rtol=0, atol=0)  # response
+    dang = np.abs(kg[:, 3] - ko[:, 3])
+    assert np.all(np.minimum(dang, 360 - dang) < 1e-2)  # degrees; the histogram weights go through expf
+    assert [int(np.float32(v).view(np.int32)) for v in res.records[:, 5]] == [k[5] for k in kps_o]
+    diff = np.abs(res.descriptors.astype(int) - desc_o.astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() < 0.01  # a rounding to the neighbouring integer here and there
+
+
+def test_descriptors_match_across_a_rotation_and_scale_change(env):
+    """SIFT behaviour, not arithmetic: most keypoints of an image are found again, with matching descriptors, in a
+    rotated and rescaled copy (checked through the GPU matcher with the reference's 0.75 ratio)."""
+    torch, C, sift = env
+    from sfm_hip import matching
+
+    h = w = 220
+    base = blob_image(h, w, 160, 5).astype(np.float64)
+    ang, sc = np.deg2rad(25.0), 1.3
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    c = (w - 1) / 2
+    xs = ((xx - c) * np.cos(ang) - (yy - c) * np.sin(ang)) / sc + c
+    ys = ((xx - c) * np.sin(ang) + (yy - c) * np.cos(ang)) / sc + c
+    x0, y0 = np.clip(np.floor(xs).astype(int), 0, w - 2), np.clip(np.floor(ys).astype(int), 0, h - 2)
+    fx, fy = np.clip(xs - x0, 0, 1), np.clip(ys - y0, 0, 1)
+    warped = (base[y0, x0] * (1 - fx) * (1 - fy) + base[y0, x0 + 1] * fx * (1 - fy) + base[y0 + 1, x0] * (1 - fx) * fy + base[y0 + 1, x0 + 1] * fx * fy)
+    inside = (xs >= 0) & (xs <= w - 1) & (ys >= 0) & (ys <= h - 1)
+    warped = np.where(inside, warped, base.mean())
+    a = sift.detect_and_compute(base.astype(np.uint8))
+    b = sift.detect_and_compute(warped.astype(np.uint8))
+    assert a.keypoints.shape[0] > 80 and b.keypoints.shape[0] > 80
+    qi, ti, _ = matching.knn_match_ratio(a.descriptors, b.descriptors, 0.75)
+    assert qi.size > 40
+    # a keypoint at p in the base image appears at R^-1-ish mapping in the warped one: invert the sampling map
+    pa = a.keypoints[qi].astype(np.float64) - c
+    pred = np.stack([(pa[:, 0] * np.cos(ang) + pa[:, 1] * np.sin(ang)) * sc + c, (-pa[:, 0] * np.sin(ang) + pa[:, 1] * np.cos(ang)) * sc + c], axis=1)
+    err = np.linalg.norm(pred - b.keypoints[ti], axis=1)
+    assert np.median(err) < 1.0 and (err < 3.0).mean() > 0.8
