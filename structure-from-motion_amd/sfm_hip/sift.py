@@ -44,7 +44,7 @@ def detect_and_compute(gray, capacity=DEFAULT_CAPACITY):
     """gray: uint8 [h][w] (host array or device tensor).  Returns a SiftResult."""
     torch = C.torch_cuda()
     lib = C.load_library()
-    g = gray if isinstance(gray, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(gray, dtype=np.uint8)).cuda()
+    g = gray if isinstance(gray, torch.Tensor) else torch.from_numpy(np.array(gray, dtype=np.uint8, order="C")).cuda()
     if g.dtype != torch.uint8 or g.dim() != 2:
         raise ValueError("gray must be a uint8 image [h][w]")
     g = g.contiguous()

@@ -152,3 +152,96 @@ def multi_view_scene(n_cams=5, n_points=900, init_pair=(1, 3), seed=0, K=K_DATAS
 
     return dict(K=K, x_pairs=x_pairs, init_pair_dict=init_pair_dict, img_paths=img_paths, find_correspondences=find_correspondences,
                 R_true=Rs, T_true=Ts, X_true=X)
+
+
+def _blob_texture(size, n_blobs, rng):
+    """A texture with structure at many scales (Gaussian blobs of random size, contrast and elongation plus fine noise),
+    float64 in [0, 255]: something a blob detector finds thousands of stable features on."""
+    tex = np.zeros((size, size))
+    for _ in range(n_blobs):
+        s = float(np.exp(rng.uniform(np.log(1.5), np.log(14.0))))
+        cx, cy, a, e = rng.uniform(0, size), rng.uniform(0, size), rng.uniform(-1, 1), rng.uniform(0.6, 1.6)
+        r = int(4 * s * max(e, 1 / e)) + 1
+        x0, x1, y0, y1 = max(int(cx) - r, 0), min(int(cx) + r + 1, size), max(int(cy) - r, 0), min(int(cy) + r + 1, size)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        yy, xx = np.mgrid[y0:y1, x0:x1]
+        tex[y0:y1, x0:x1] += a * np.exp(-(((xx - cx) / e) ** 2 + ((yy - cy) * e) ** 2) / (2 * s * s))
+    tex += rng.normal(0, 0.02, tex.shape)
+    lo, hi = np.percentile(tex, [0.5, 99.5])
+    return np.clip((tex - lo) / (hi - lo), 0, 1) * 255.0
+
+
+def _sample(tex, u, v):
+    """Bilinear lookup of tex at fractional (column u, row v); coordinates are clamped to the texture."""
+    h, w = tex.shape
+    u = np.clip(u, 0, w - 1.001)
+    v = np.clip(v, 0, h - 1.001)
+    u0, v0 = np.floor(u).astype(int), np.floor(v).astype(int)
+    fu, fv = u - u0, v - v0
+    return (tex[v0, u0] * (1 - fu) * (1 - fv) + tex[v0, u0 + 1] * fu * (1 - fv) + tex[v0 + 1, u0] * (1 - fu) * fv
+            + tex[v0 + 1, u0 + 1] * fu * fv)
+
+
+def render_views(n_cams=10, width=1936, height=1296, seed=0, K=None, texture_size=3072, n_blobs=9000):
+    """Images of a piecewise planar textured scene seen by n_cams cameras moving sideways: a large tilted background
+    plane z = 6 + 0.2 x and a fronto-parallel rectangle at z = 4.6 in front of it (so the scene is not one plane).
+    Returns dict(images uint8 [n][h][w], K, R_true, T_true); camera c maps X to K (R_c X + T_c).  With the default K the
+    intrinsics are dataset 5's scaled to the requested image width."""
+    rng = np.random.default_rng(seed)
+    if K is None:
+        s = width / 1936.0
+        K = [[2489.14 * s, 0, 968 * s], [0, 2489.14 * s, height / 2.0], [0, 0, 1]]
+    Kn = np.asarray(K, float)
+    tex_bg = _blob_texture(texture_size, n_blobs, rng)
+    tex_fg = _blob_texture(texture_size // 3, n_blobs // 6, rng)
+    ext_bg = 4.5  # the background texture covers x, y in [-ext, ext]
+    fg = (-1.3, 0.2, -0.9, 0.7, 4.6)  # x0, x1, y0, y1, z of the front rectangle
+    Rs, Ts = [np.eye(3)], [np.zeros(3)]
+    for c in range(1, n_cams):
+        Rs.append(Rs[-1] @ rot_y(0.022 + 0.002 * (c % 3)) @ rot_x(0.004 * (-1) ** c))
+        Ts.append(np.array([-0.16 * c, 0.012 * c, 0.008 * c]))
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    rays_cam = np.linalg.inv(Kn) @ np.stack([xx.ravel(), yy.ravel(), np.ones(xx.size)])
+    images = np.empty((n_cams, height, width), np.uint8)
+    for c in range(n_cams):
+        d = Rs[c].T @ rays_cam
+        C0 = -Rs[c].T @ Ts[c]
+        # background: n . X = 6 with n = (-0.2, 0, 1)
+        n = np.array([-0.2, 0.0, 1.0])
+        t_bg = (6.0 - n @ C0) / (n @ d)
+        X = C0[:, None] + d * t_bg
+        img = _sample(tex_bg, (X[0] + ext_bg) / (2 * ext_bg) * (texture_size - 1), (X[1] + ext_bg) / (2 * ext_bg) * (texture_size - 1))
+        # front rectangle: z = fg[4]
+        t_fg = (fg[4] - C0[2]) / d[2]
+        Xf = C0[:, None] + d * t_fg
+        hit = (t_fg > 0) & (Xf[0] >= fg[0]) & (Xf[0] <= fg[1]) & (Xf[1] >= fg[2]) & (Xf[1] <= fg[3])
+        ts = tex_fg.shape[0] - 1
+        img_fg = _sample(tex_fg, (Xf[0] - fg[0]) / (fg[1] - fg[0]) * ts, (Xf[1] - fg[2]) / (fg[3] - fg[2]) * ts)
+        img = np.where(hit, img_fg, img)
+        img = img + rng.normal(0, 1.0, img.shape)  # sensor noise
+        images[c] = np.clip(np.rint(img), 0, 255).astype(np.uint8).reshape(height, width)
+    return dict(images=images, K=K, R_true=Rs, T_true=Ts)
+
+
+def write_image_dataset(directory, views, init_pair=(4, 6)):
+    """Writes the rendered views as PNG files with a cfg.yml in the layout of the reference's data/<dataset> folders
+    (camera.focal_length, camera.principal_point, image_file_names, initial_pair).  Returns the image paths."""
+    import os
+
+    from PIL import Image
+
+    os.makedirs(directory, exist_ok=True)
+    names = [f"view_{c:02d}.png" for c in range(len(views["images"]))]
+    for name, img in zip(names, views["images"]):
+        Image.fromarray(img, mode="L").save(os.path.join(directory, name))
+    K = views["K"]
+    with open(os.path.join(directory, "cfg.yml"), "w") as f:
+        f.write("camera:\n")
+        f.write(f"  focal_length: [{K[0][0]}, {K[1][1]}]\n")
+        f.write(f"  principal_point: [{K[0][2]}, {K[1][2]}]\n")
+        f.write("image_file_names:\n")
+        for name in names:
+            f.write(f"  - {name}\n")
+        f.write(f"initial_pair: [{init_pair[0]}, {init_pair[1]}]\n")
+    return [os.path.join(directory, n) for n in names]
