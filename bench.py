@@ -454,6 +454,85 @@ def e2e(torch, synthetic, orc, seed, with_cpu):
     return out
 
 
+def e2e_images(torch, synthetic, seed, n_cams=10, width=1936, height=1296):
+    """The whole pipeline from image FILES, shaped like dataset 5 (10 images of 1936 x 1296, its intrinsics): rendered
+    views of a textured two-plane scene are written as PNG files + cfg.yml, then the command-line driver's stages run:
+    image decoding, SIFT detection + description (GPU), descriptor matching (GPU), geometry (GPU).  The reference's own
+    dataset cannot be used (its images may not be copied and do not exist on the GPU box) and OpenCV is absent, so this is
+    the measurable stand-in for 'dataset-5 end-to-end seconds'; rotations are checked against the renderer's ground truth."""
+    import tempfile
+
+    from sfm_hip import matching, pipeline, sift
+    from sfm_hip.extract_sift import process_sift_for_image_pairs
+    from sfm_hip.io import get_data
+
+    t0 = time.perf_counter()
+    views = synthetic.render_views(n_cams=n_cams, width=width, height=height, seed=seed)
+    render_s = time.perf_counter() - t0
+    out = {"workload": f"{n_cams} rendered images of {width} x {height} (dataset-5 intrinsics), PNG files + cfg.yml, 1 px threshold",
+           "render_seconds_not_counted": render_s}
+    with tempfile.TemporaryDirectory() as tmp:
+        where = os.path.join(tmp, "data", "syn")
+        synthetic.write_image_dataset(where, views, init_pair=(4, 6) if n_cams >= 7 else (0, 1))
+        sift.detect_and_compute(views["images"][0][:256, :256])  # warm-up: library load, allocator
+        best = None
+        for rep in range(2):
+            matching._features.clear()
+            for f in os.listdir(where):
+                if f.endswith(".pkl"):
+                    os.remove(os.path.join(where, f))
+            stage = {"decode": 0.0, "sift": 0.0, "images_detected": 0}
+            orig_read, orig_detect = sift.read_gray, sift.detect_and_compute
+
+            def timed_read(*a, **k):
+                t = time.perf_counter()
+                r = orig_read(*a, **k)
+                stage["decode"] += time.perf_counter() - t
+                return r
+
+            def timed_detect(*a, **k):
+                t = time.perf_counter()
+                r = orig_detect(*a, **k)
+                torch.cuda.synchronize()
+                stage["sift"] += time.perf_counter() - t
+                stage["images_detected"] += 1
+                return r
+
+            sift.read_gray, sift.detect_and_compute = timed_read, timed_detect
+            try:
+                np.random.seed(seed + 31)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                K, img_paths, init_pair = get_data(where)
+                x_pairs, init_pair_dict = process_sift_for_image_pairs(img_paths=img_paths, init_pair=init_pair, dataset="syn")
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                front = dict(stage)
+                res = pipeline.run_geometry(K, x_pairs, init_pair_dict, img_paths, 1.0)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+            finally:
+                sift.read_gray, sift.detect_and_compute = orig_read, orig_detect
+            if best is None or t2 - t0 < best["total_seconds"]:
+                feats = [v[0].shape[0] for v in matching._features.values()]
+                best = {"total_seconds": t2 - t0, "front_end_seconds": t1 - t0, "image_decode_seconds": front["decode"],
+                        "sift_seconds": front["sift"], "images_detected": stage["images_detected"],
+                        "pair_matching_and_caches_seconds": t1 - t0 - front["decode"] - front["sift"],
+                        "geometry_seconds_incl_2d3d_matching": t2 - t1,
+                        "decode_and_sift_seconds_inside_geometry": stage["decode"] + stage["sift"] - front["decode"] - front["sift"], "keypoints_per_image_min_max": [int(min(feats)), int(max(feats))],
+                        "matches_per_pair_min_max": [int(min(x.shape[1] for x in x_pairs)), int(max(x.shape[1] for x in x_pairs))]}
+        R = res["absolute_rotations"]
+        errs = []
+        for c in range(1, n_cams):
+            Rt = views["R_true"][c] @ views["R_true"][c - 1].T
+            Rr = R[c] @ R[c - 1].T
+            errs.append(float(np.degrees(np.arccos(np.clip((np.trace(Rt.T @ Rr) - 1) / 2, -1, 1)))))
+        best["relative_rotation_errors_degrees"] = [round(e, 3) for e in errs]
+    out.update(best)
+    out["note"] = "best of 2 repetitions; every image is decoded and detected once (the reference detects each image three times)"
+    return out
+
+
 C5_MATCHES, C5_HYPOTHESES, C5_BLOCK = 200000, 100000000, 12500000
 
 
@@ -583,13 +662,15 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the T-RANSAC / LM / triangulation timings")
     ap.add_argument("--e2e", action="store_true", help="only run the synthetic dataset-5-shaped end-to-end geometry and print it")
     ap.add_argument("--e2e-cpu", action="store_true", help="with --e2e: also time the NumPy oracle end to end (minutes) and compare")
+    ap.add_argument("--e2e-images", action="store_true",
+                    help="only run the pipeline from rendered image files shaped like dataset 5 (SIFT + matching + geometry) and print it")
     ap.add_argument("--sweep", action="store_true", help="only run the match-count sweep (2k..200k matches) and print it")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     workload = args.workload if args.workload != "auto" else ("c2" if world_env == 1 else "c5")
     all_cores = None
-    side_runs = args.e2e or args.sweep
+    side_runs = args.e2e or args.sweep or args.e2e_images
     if args.cpu_all_cores < 0:
         try:
             share = int(os.environ.get("OMP_NUM_THREADS", "0"))
@@ -625,6 +706,9 @@ def main():
 
     if args.e2e:
         print(json.dumps({"e2e": e2e(torch, synthetic, orc, args.seed, args.e2e_cpu)}))
+        return
+    if args.e2e_images:
+        print(json.dumps({"e2e_images": e2e_images(torch, synthetic, args.seed)}))
         return
     if args.sweep:
         print(json.dumps({"sweep": sweep(torch, ops, _capi, synthetic, orc, args.seed)}))

@@ -52,12 +52,15 @@ def image_features(img_path, mode):
     """SIFT keypoints (float32 [n][2]) and descriptors (uint8 [n][128]) of one image, detected once per (path, mode).
     mode "bgr2gray": cv2.imread + cvtColor (src/extract_sift.py:104-114); mode "grayscale": cv2.imread(IMREAD_GRAYSCALE)
     (src/utils.py:78-80)."""
-    key = (os.path.abspath(img_path), mode)
+    if mode not in ("bgr2gray", "grayscale"):
+        raise ValueError(mode)
+    # the two read modes only differ inside OpenCV's decoders; every other decoder gives one gray image per file
+    key = (os.path.abspath(img_path), mode if os.environ.get("SFM_HIP_SIFT", "hip") == "cv2" else "gray")
     if key in _features:
         return _features[key]
     cache = None
     if FEATURE_CACHE_DIR:
-        cache = os.path.join(FEATURE_CACHE_DIR, f"{os.path.basename(img_path)}.{mode}.sift.npz")
+        cache = os.path.join(FEATURE_CACHE_DIR, f"{os.path.basename(img_path)}.{key[1]}.sift.npz")
         if os.path.exists(cache):
             with np.load(cache) as z:
                 _features[key] = (z["keypoints"], z["descriptors"])

@@ -185,18 +185,19 @@ def _sample(tex, u, v):
 
 def render_views(n_cams=10, width=1936, height=1296, seed=0, K=None, texture_size=3072, n_blobs=9000):
     """Images of a piecewise planar textured scene seen by n_cams cameras moving sideways: a large tilted background
-    plane z = 6 + 0.2 x and a fronto-parallel rectangle at z = 4.6 in front of it (so the scene is not one plane).
-    Returns dict(images uint8 [n][h][w], K, R_true, T_true); camera c maps X to K (R_c X + T_c).  With the default K the
-    intrinsics are dataset 5's scaled to the requested image width."""
+    plane z = 6 + 0.2 x and four fronto-parallel rectangles at depths 4.2 .. 5.5 in front of it (so the scene is far from
+    one plane).  Returns dict(images uint8 [n][h][w], K, R_true, T_true); camera c maps X to K (R_c X + T_c).  With the
+    default K the intrinsics are dataset 5's scaled to the requested image width."""
     rng = np.random.default_rng(seed)
     if K is None:
         s = width / 1936.0
         K = [[2489.14 * s, 0, 968 * s], [0, 2489.14 * s, height / 2.0], [0, 0, 1]]
     Kn = np.asarray(K, float)
     tex_bg = _blob_texture(texture_size, n_blobs, rng)
-    tex_fg = _blob_texture(texture_size // 3, n_blobs // 6, rng)
     ext_bg = 4.5  # the background texture covers x, y in [-ext, ext]
-    fg = (-1.3, 0.2, -0.9, 0.7, 4.6)  # x0, x1, y0, y1, z of the front rectangle
+    # x0, x1, y0, y1, z of the front rectangles (nearest last, so that it is drawn over the others)
+    rects = [(-0.2, 0.9, -0.1, 0.9, 5.5), (-2.1, -1.0, -0.2, 0.8, 5.0), (-1.4, -0.1, -1.0, -0.15, 4.6), (0.1, 1.2, -0.9, -0.2, 4.2)]
+    tex_fg = [_blob_texture(texture_size // 3, n_blobs // 6, rng) for _ in rects]
     Rs, Ts = [np.eye(3)], [np.zeros(3)]
     for c in range(1, n_cams):
         Rs.append(Rs[-1] @ rot_y(0.022 + 0.002 * (c % 3)) @ rot_x(0.004 * (-1) ** c))
@@ -212,13 +213,13 @@ def render_views(n_cams=10, width=1936, height=1296, seed=0, K=None, texture_siz
         t_bg = (6.0 - n @ C0) / (n @ d)
         X = C0[:, None] + d * t_bg
         img = _sample(tex_bg, (X[0] + ext_bg) / (2 * ext_bg) * (texture_size - 1), (X[1] + ext_bg) / (2 * ext_bg) * (texture_size - 1))
-        # front rectangle: z = fg[4]
-        t_fg = (fg[4] - C0[2]) / d[2]
-        Xf = C0[:, None] + d * t_fg
-        hit = (t_fg > 0) & (Xf[0] >= fg[0]) & (Xf[0] <= fg[1]) & (Xf[1] >= fg[2]) & (Xf[1] <= fg[3])
-        ts = tex_fg.shape[0] - 1
-        img_fg = _sample(tex_fg, (Xf[0] - fg[0]) / (fg[1] - fg[0]) * ts, (Xf[1] - fg[2]) / (fg[3] - fg[2]) * ts)
-        img = np.where(hit, img_fg, img)
+        for fg, tex in zip(rects, tex_fg):
+            t_fg = (fg[4] - C0[2]) / d[2]
+            Xf = C0[:, None] + d * t_fg
+            hit = (t_fg > 0) & (Xf[0] >= fg[0]) & (Xf[0] <= fg[1]) & (Xf[1] >= fg[2]) & (Xf[1] <= fg[3])
+            ts = tex.shape[0] - 1
+            img_fg = _sample(tex, (Xf[0] - fg[0]) / (fg[1] - fg[0]) * ts, (Xf[1] - fg[2]) / (fg[3] - fg[2]) * ts)
+            img = np.where(hit, img_fg, img)
         img = img + rng.normal(0, 1.0, img.shape)  # sensor noise
         images[c] = np.clip(np.rint(img), 0, 255).astype(np.uint8).reshape(height, width)
     return dict(images=images, K=K, R_true=Rs, T_true=Ts)

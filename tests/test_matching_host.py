@@ -39,6 +39,7 @@ def fake_cv2(monkeypatch):
 def test_features_are_detected_once_per_image_and_mode(fake_cv2, tmp_path, monkeypatch):
     from sfm_hip import matching
 
+    monkeypatch.setenv("SFM_HIP_SIFT", "cv2")  # the OpenCV detector, for users who have it and want the reference's features
     monkeypatch.setattr(matching, "_features", {})
     monkeypatch.setattr(matching, "FEATURE_CACHE_DIR", str(tmp_path / "cache"))
     kp, d = matching.image_features("/data/img_001.jpg", "grayscale")
@@ -54,6 +55,33 @@ def test_features_are_detected_once_per_image_and_mode(fake_cv2, tmp_path, monke
     assert sorted(p.name for p in (tmp_path / "cache").iterdir()) == ["img_001.jpg.bgr2gray.sift.npz", "img_001.jpg.grayscale.sift.npz"]
     with pytest.raises(ValueError):
         matching.image_features("/data/img_002.jpg", "other")
+
+
+def test_gpu_detector_is_the_default_and_runs_once_per_file(tmp_path, monkeypatch):
+    """Without SFM_HIP_SIFT=cv2 the GPU detector runs (stubbed here: no GPU on this machine), and the two read modes of the
+    reference share one feature set per file, because only OpenCV's decoders tell them apart."""
+    from sfm_hip import matching, sift
+
+    calls = {"read": [], "detect": 0}
+
+    def read_gray(path, mode):
+        calls["read"].append((path, mode))
+        return np.zeros((8, 8), np.uint8)
+
+    def detect(gray, capacity=0):
+        calls["detect"] += 1
+        return sift.SiftResult(np.zeros((3, 6), np.float32), np.zeros((3, 128), np.uint8))
+
+    monkeypatch.delenv("SFM_HIP_SIFT", raising=False)
+    monkeypatch.setattr(matching, "_features", {})
+    monkeypatch.setattr(matching, "FEATURE_CACHE_DIR", None)
+    monkeypatch.setattr(sift, "read_gray", read_gray)
+    monkeypatch.setattr(sift, "detect_and_compute", detect)
+    kp, d = matching.image_features("/data/a.png", "bgr2gray")
+    kp2, _ = matching.image_features("/data/a.png", "grayscale")
+    assert kp2 is kp and calls["detect"] == 1 and kp.shape == (3, 2) and d.shape == (3, 128)
+    matching.image_features("/data/b.png", "grayscale")
+    assert calls["detect"] == 2
 
 
 def test_matcher_refuses_to_run_without_gpu(fake_cv2):
