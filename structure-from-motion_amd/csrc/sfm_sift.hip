@@ -10,14 +10,14 @@
 // cosf / sinf can differ in the last place.
 //
 // Stages and their shapes:
-//   pyramid      one thread per pixel; separable Gaussian (rows through LDS, columns coalesced along x),
-//                nearest-neighbour decimation, differences of neighbouring layers;
+//   pyramid      separable Gaussian (rows and 64 x 64 column tiles staged in LDS with their reflected margins; the
+//                column pass also writes the difference to the previous layer), nearest-neighbour decimation;
 //   extrema      one thread per interior pixel and layer: 26-neighbour test, candidates appended through a counter;
 //   refinement   one thread per candidate: quadratic fit (<= 5 steps), contrast and edge tests, orientation
 //                histogram kept in LDS as [bin][lane] (no bank conflicts, sequential float32 sums per keypoint);
-//   description  one thread per keypoint, its 4 x 4 x 10 histogram in LDS as [bin][lane] (40 KB per wave): the
-//                samples of a keypoint are accumulated one after the other, so descriptors do not depend on how
-//                waves are scheduled.
+//   description  16 lanes per keypoint, each with its own 4 x 4 x 10 histogram in LDS as [bin][lane] (40 KB per wave)
+//                over every 16th window row; the partial histograms are added in a fixed order, so descriptors do
+//                not depend on how waves are scheduled.
 // The order in which candidates and keypoints are appended is not deterministic; the host sorts them with OpenCV's
 // keypoint order before duplicates are removed, which makes the final list deterministic.
 #include <hip/hip_runtime.h>
@@ -154,13 +154,31 @@ __global__ __launch_bounds__(kBlock) void blur_rows_kernel(const float* __restri
   dst[(long long)y * w + x] = acc;
 }
 
-__global__ __launch_bounds__(kBlock) void blur_cols_kernel(const float* __restrict__ src, int w, int h, Taps taps, float* __restrict__ dst) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= w) return;
+// one workgroup = a tile of 64 columns x 64 rows staged in LDS with the reflected margins above and below; a thread
+// owns one column and 16 consecutive rows.  When `prev` is given (the Gaussian image this blur started from) the
+// difference image new - prev is written as well.
+constexpr int kColTile = 64;
+__global__ __launch_bounds__(kBlock) void blur_cols_kernel(const float* __restrict__ src, int w, int h, Taps taps, float* __restrict__ dst,
+                                                           const float* __restrict__ prev, float* __restrict__ diff) {
+  __shared__ float tile[kColTile + kMaxTaps][kColTile];
   const int r = (taps.n - 1) / 2;
-  float acc = src[(long long)reflect101(y - r, h) * w + x] * taps.k[0];
-  for (int t = 1; t < taps.n; ++t) acc = acc + src[(long long)reflect101(y + t - r, h) * w + x] * taps.k[t];
-  dst[(long long)y * w + x] = acc;
+  const int x0 = blockIdx.x * kColTile, y0 = blockIdx.y * kColTile;
+  const int cx = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int x = x0 + cx;
+  const int xs = min(x, w - 1);
+  for (int i = part; i < kColTile + 2 * r; i += kBlock / 64) tile[i][cx] = src[(long long)reflect101(y0 + i - r, h) * w + xs];
+  __syncthreads();
+  if (x >= w) return;
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const int ly = part * 16 + j, y = y0 + ly;
+    if (y >= h) break;
+    float acc = tile[ly][cx] * taps.k[0];
+    for (int t = 1; t < taps.n; ++t) acc = acc + tile[ly + t][cx] * taps.k[t];
+    const long long p = (long long)y * w + x;
+    dst[p] = acc;
+    if (diff) diff[p] = acc - prev[p];
+  }
 }
 
 // resize(src, Size(W / 2, H / 2), INTER_NEAREST)
@@ -170,11 +188,6 @@ __global__ __launch_bounds__(kBlock) void downsample2_kernel(const float* __rest
   const int sx = min((int)floor((double)x * ((double)W / (double)w)), W - 1);
   const int sy = min((int)floor((double)y * ((double)H / (double)h)), H - 1);
   dst[(long long)y * w + x] = src[(long long)sy * W + sx];
-}
-
-__global__ __launch_bounds__(kBlock) void subtract_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float* __restrict__ out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = a[i] - b[i];
 }
 
 // grid = (x tiles, interior rows, layers 1..kLayers); candidate = (octave, layer, r, c)
@@ -380,109 +393,128 @@ __global__ __launch_bounds__(64) void refine_orient_kernel(const float* __restri
   }
 }
 
-// one thread per keypoint (final list, image coordinates); histogram [4][4][10] in LDS as [bin][lane]
+// 16 lanes per keypoint (final list, image coordinates), 4 keypoints per wave.  Lane `sub` of a keypoint accumulates
+// the window rows di = -radius + sub, + 16, ... into its own 4 x 4 x 10 histogram (LDS, [bin][lane]); the 16 partial
+// histograms are then added in lane order, lane `sub` finishing cell `sub` of the 4 x 4 grid.  Every sum has a fixed
+// order, so a descriptor does not depend on how waves are scheduled.
 __global__ __launch_bounds__(64) void describe_kernel(const float* __restrict__ ws, PlanDev plan, const float* __restrict__ kps, int n,
                                                       uint8_t* __restrict__ desc) {
-  constexpr int d = 4, nb = 8, kCell = nb + 2;
+  constexpr int d = 4, nb = 8, kCell = nb + 2, kSub = 16;
   __shared__ float hist[d * d * kCell][64];
-  const int lane = threadIdx.x;
-  const int i = blockIdx.x * 64 + lane;
-  if (i >= n) return;
-  const float* k = kps + 6LL * i;
-  const int packed = __float_as_int(k[5]);
-  int octave = packed & 255;
-  const int layer = (packed >> 8) & 255;
-  octave = octave < 128 ? octave : (-128 | octave);
-  const float scale = octave >= 0 ? 1.0f / (float)(1 << octave) : (float)(1 << -octave);
-  const int o = octave + 1;  // firstOctave = -1
-  const int w = plan.W[o], h = plan.H[o];
-  const float* img = ws + plan.gauss[o] + (long long)layer * w * h;
-  const float ptx = k[0] * scale, pty = k[1] * scale;
-  float ori = 360.0f - k[3];
-  if (fabsf(ori - 360.0f) < 1.1920929e-07f) ori = 0.0f;
-  const float scl = (k[2] * scale) * 0.5f;
-  const int px = (int)rintf(ptx), py = (int)rintf(pty);
-  float cos_t = (float)cos((double)ori * (M_PI / 180.0)), sin_t = (float)sin((double)ori * (M_PI / 180.0));
-  const float bins_per_rad = (float)(nb / 360.0);
-  const float exp_scale = -1.0f / (float)(d * d * 0.5);
-  const float hist_width = 3.0f * scl;
-  int radius = (int)lrint((double)hist_width * 1.4142135623730951 * (d + 1) * 0.5);
-  radius = min(radius, (int)sqrt((double)w * w + (double)h * h));
-  cos_t = cos_t / hist_width;
-  sin_t = sin_t / hist_width;
+  __shared__ float part[64];
+  const int lane = threadIdx.x, sub = lane & (kSub - 1), group = lane - sub;
+  const int i = blockIdx.x * (64 / kSub) + lane / kSub;
+  const bool valid = i < n;
   for (int b = 0; b < d * d * kCell; ++b) hist[b][lane] = 0.0f;
-  for (int di = -radius; di <= radius; ++di)
-    for (int dj = -radius; dj <= radius; ++dj) {
-      const float c_rot = (float)dj * cos_t - (float)di * sin_t;
-      const float r_rot = (float)dj * sin_t + (float)di * cos_t;
-      float rbin = (r_rot + (float)(d / 2)) - 0.5f;
-      float cbin = (c_rot + (float)(d / 2)) - 0.5f;
-      const int r = py + di, c = px + dj;
-      if (!(rbin > -1.0f && rbin < (float)d && cbin > -1.0f && cbin < (float)d && r > 0 && r < h - 1 && c > 0 && c < w - 1)) continue;
-      const long long p = (long long)r * w + c;
-      const float dx = img[p + 1] - img[p - 1];
-      const float dy = img[p - w] - img[p + w];
-      const float wgt = expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-      const float ang = fast_atan2_deg(dy, dx);
-      const float mag = sqrtf(dx * dx + dy * dy) * wgt;
-      float obin = (ang - ori) * bins_per_rad;
-      const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
-      int o0 = (int)floorf(obin);
-      rbin -= (float)r0;
-      cbin -= (float)c0;
-      obin -= (float)o0;
-      if (o0 < 0) o0 += nb;
-      if (o0 >= nb) o0 -= nb;
-      const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-      const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
-      const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-      const float v111 = v_rc11 * obin, v110 = v_rc11 - v111;
-      const float v101 = v_rc10 * obin, v100 = v_rc10 - v101;
-      const float v011 = v_rc01 * obin, v010 = v_rc01 - v011;
-      const float v001 = v_rc00 * obin, v000 = v_rc00 - v001;
-      // cells (r0, c0) .. (r0 + 1, c0 + 1) with r0, c0 in [-1, d - 1]; the cells outside [0, d) never reach the descriptor
-      const bool ra = r0 >= 0, rb = r0 + 1 < d, ca = c0 >= 0, cb = c0 + 1 < d;
-      const int base = (r0 * d + c0) * kCell + o0;
-      if (ra && ca) {
-        hist[base][lane] = hist[base][lane] + v000;
-        hist[base + 1][lane] = hist[base + 1][lane] + v001;
+  if (valid) {
+    const float* k = kps + 6LL * i;
+    const int packed = __float_as_int(k[5]);
+    int octave = packed & 255;
+    const int layer = (packed >> 8) & 255;
+    octave = octave < 128 ? octave : (-128 | octave);
+    const float scale = octave >= 0 ? 1.0f / (float)(1 << octave) : (float)(1 << -octave);
+    const int o = octave + 1;  // firstOctave = -1
+    const int w = plan.W[o], h = plan.H[o];
+    const float* img = ws + plan.gauss[o] + (long long)layer * w * h;
+    const float ptx = k[0] * scale, pty = k[1] * scale;
+    float ori = 360.0f - k[3];
+    if (fabsf(ori - 360.0f) < 1.1920929e-07f) ori = 0.0f;
+    const float scl = (k[2] * scale) * 0.5f;
+    const int px = (int)rintf(ptx), py = (int)rintf(pty);
+    float cos_t = (float)cos((double)ori * (M_PI / 180.0)), sin_t = (float)sin((double)ori * (M_PI / 180.0));
+    const float bins_per_rad = (float)(nb / 360.0);
+    const float exp_scale = -1.0f / (float)(d * d * 0.5);
+    const float hist_width = 3.0f * scl;
+    int radius = (int)lrint((double)hist_width * 1.4142135623730951 * (d + 1) * 0.5);
+    radius = min(radius, (int)sqrt((double)w * w + (double)h * h));
+    cos_t = cos_t / hist_width;
+    sin_t = sin_t / hist_width;
+    for (int di = -radius + sub; di <= radius; di += kSub)
+      for (int dj = -radius; dj <= radius; ++dj) {
+        const float c_rot = (float)dj * cos_t - (float)di * sin_t;
+        const float r_rot = (float)dj * sin_t + (float)di * cos_t;
+        float rbin = (r_rot + (float)(d / 2)) - 0.5f;
+        float cbin = (c_rot + (float)(d / 2)) - 0.5f;
+        const int r = py + di, c = px + dj;
+        if (!(rbin > -1.0f && rbin < (float)d && cbin > -1.0f && cbin < (float)d && r > 0 && r < h - 1 && c > 0 && c < w - 1)) continue;
+        const long long p = (long long)r * w + c;
+        const float dx = img[p + 1] - img[p - 1];
+        const float dy = img[p - w] - img[p + w];
+        const float wgt = expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+        const float ang = fast_atan2_deg(dy, dx);
+        const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+        float obin = (ang - ori) * bins_per_rad;
+        const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+        int o0 = (int)floorf(obin);
+        rbin -= (float)r0;
+        cbin -= (float)c0;
+        obin -= (float)o0;
+        if (o0 < 0) o0 += nb;
+        if (o0 >= nb) o0 -= nb;
+        const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+        const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+        const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+        const float v111 = v_rc11 * obin, v110 = v_rc11 - v111;
+        const float v101 = v_rc10 * obin, v100 = v_rc10 - v101;
+        const float v011 = v_rc01 * obin, v010 = v_rc01 - v011;
+        const float v001 = v_rc00 * obin, v000 = v_rc00 - v001;
+        // cells (r0, c0) .. (r0 + 1, c0 + 1) with r0, c0 in [-1, d - 1]; the cells outside [0, d) never reach the descriptor
+        const bool ra = r0 >= 0, rb = r0 + 1 < d, ca = c0 >= 0, cb = c0 + 1 < d;
+        const int base = (r0 * d + c0) * kCell + o0;
+        if (ra && ca) {
+          hist[base][lane] = hist[base][lane] + v000;
+          hist[base + 1][lane] = hist[base + 1][lane] + v001;
+        }
+        if (ra && cb) {
+          hist[base + kCell][lane] = hist[base + kCell][lane] + v010;
+          hist[base + kCell + 1][lane] = hist[base + kCell + 1][lane] + v011;
+        }
+        if (rb && ca) {
+          hist[base + d * kCell][lane] = hist[base + d * kCell][lane] + v100;
+          hist[base + d * kCell + 1][lane] = hist[base + d * kCell + 1][lane] + v101;
+        }
+        if (rb && cb) {
+          hist[base + (d + 1) * kCell][lane] = hist[base + (d + 1) * kCell][lane] + v110;
+          hist[base + (d + 1) * kCell + 1][lane] = hist[base + (d + 1) * kCell + 1][lane] + v111;
+        }
       }
-      if (ra && cb) {
-        hist[base + kCell][lane] = hist[base + kCell][lane] + v010;
-        hist[base + kCell + 1][lane] = hist[base + kCell + 1][lane] + v011;
-      }
-      if (rb && ca) {
-        hist[base + d * kCell][lane] = hist[base + d * kCell][lane] + v100;
-        hist[base + d * kCell + 1][lane] = hist[base + d * kCell + 1][lane] + v101;
-      }
-      if (rb && cb) {
-        hist[base + (d + 1) * kCell][lane] = hist[base + (d + 1) * kCell][lane] + v110;
-        hist[base + (d + 1) * kCell + 1][lane] = hist[base + (d + 1) * kCell + 1][lane] + v111;
-      }
-    }
-  // orientation bins nb and nb + 1 wrap onto 0 and 1; then normalise, clip at 0.2, renormalise, scale by 512, saturate
-  float nrm2 = 0.0f;
-  for (int cell = 0; cell < d * d; ++cell) {
-    float* hc0 = &hist[cell * kCell][lane];
-    hc0[0] = hc0[0] + hc0[nb * 64];
-    hc0[64] = hc0[64] + hc0[(nb + 1) * 64];
-    for (int b = 0; b < nb; ++b) nrm2 = nrm2 + hc0[b * 64] * hc0[b * 64];
   }
-  const float thr = sqrtf(nrm2) * 0.2f;
-  nrm2 = 0.0f;
-  for (int cell = 0; cell < d * d; ++cell)
-    for (int b = 0; b < nb; ++b) {
-      float* v = &hist[cell * kCell + b][lane];
-      *v = fminf(*v, thr);
-      nrm2 = nrm2 + *v * *v;
-    }
-  const float s = 512.0f / fmaxf(sqrtf(nrm2), 1.1920929e-07f);
-  uint8_t* out = desc + 128LL * i;
-  for (int cell = 0; cell < d * d; ++cell)
-    for (int b = 0; b < nb; ++b) {
-      const float v = rintf(hist[cell * kCell + b][lane] * s);
-      out[cell * nb + b] = (uint8_t)fminf(fmaxf(v, 0.0f), 255.0f);
-    }
+  __syncthreads();
+  // lane `sub` finishes cell `sub`: the 16 partial histograms in lane order, then the orientation bins nb and nb + 1
+  // wrap onto 0 and 1
+  float cell[kCell];
+#pragma unroll
+  for (int b = 0; b < kCell; ++b) {
+    float v = hist[sub * kCell + b][group];
+    for (int l = 1; l < kSub; ++l) v = v + hist[sub * kCell + b][group + l];
+    cell[b] = v;
+  }
+  cell[0] = cell[0] + cell[nb];
+  cell[1] = cell[1] + cell[nb + 1];
+  // normalise, clip at 0.2, renormalise, scale by 512, saturate; squared norms: per cell, then over the cells in order
+  auto group_sum = [&](float mine) {
+    __syncthreads();
+    part[lane] = mine;
+    __syncthreads();
+    float t = part[group];
+    for (int l = 1; l < kSub; ++l) t = t + part[group + l];
+    return t;
+  };
+  float sq = 0.0f;
+#pragma unroll
+  for (int b = 0; b < nb; ++b) sq = sq + cell[b] * cell[b];
+  const float thr = sqrtf(group_sum(sq)) * 0.2f;
+  sq = 0.0f;
+#pragma unroll
+  for (int b = 0; b < nb; ++b) {
+    cell[b] = fminf(cell[b], thr);
+    sq = sq + cell[b] * cell[b];
+  }
+  const float s = 512.0f / fmaxf(sqrtf(group_sum(sq)), 1.1920929e-07f);
+  if (!valid) return;
+  uint8_t* out = desc + 128LL * i + sub * nb;
+#pragma unroll
+  for (int b = 0; b < nb; ++b) out[b] = (uint8_t)fminf(fmaxf(rintf(cell[b] * s), 0.0f), 255.0f);
 }
 
 PlanDev to_dev(const Plan& p) {
@@ -498,12 +530,12 @@ PlanDev to_dev(const Plan& p) {
 
 inline unsigned div_up(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
-int launch_blur(const float* src, float* tmp, float* dst, int w, int h, double sigma, hipStream_t st) {
+int launch_blur(const float* src, float* tmp, float* dst, int w, int h, double sigma, float* diff, hipStream_t st) {
   Taps taps;
   const int rc = gaussian_taps(sigma, &taps);
   if (rc) return rc;
   blur_rows_kernel<<<dim3(div_up(w, kBlock), h), kBlock, 0, st>>>(src, w, h, taps, tmp);
-  blur_cols_kernel<<<dim3(div_up(w, kBlock), h), kBlock, 0, st>>>(tmp, w, h, taps, dst);
+  blur_cols_kernel<<<dim3(div_up(w, kColTile), div_up(h, kColTile)), kBlock, 0, st>>>(tmp, w, h, taps, dst, diff ? src : nullptr, diff);
   return check_launch();
 }
 
@@ -555,7 +587,7 @@ int sfm_sift_detect(const uint8_t* gray, int32_t w, int32_t h, void* workspace, 
   // the input is taken to carry a blur of 0.5 (1.0 after doubling): bring the base image to sigma
   double sig_diff2 = kSigmaD * kSigmaD - 0.5 * 0.5 * 4.0;
   if (sig_diff2 < 0.01) sig_diff2 = 0.01;
-  int rc = launch_blur(ws + p.tmp_a, ws + p.tmp_b, ws + p.gauss[0], W0, H0, sqrt(sig_diff2), st);
+  int rc = launch_blur(ws + p.tmp_a, ws + p.tmp_b, ws + p.gauss[0], W0, H0, sqrt(sig_diff2), nullptr, st);
   if (rc) return rc;
   double sig[kGauss];
   sig[0] = kSigmaD;
@@ -574,12 +606,10 @@ int sfm_sift_detect(const uint8_t* gray, int32_t w, int32_t h, void* workspace, 
       downsample2_kernel<<<dim3(div_up(W, kBlock), H), kBlock, 0, st>>>(src, p.W[o - 1], p.H[o - 1], W, H, g);
       SIFT_TRY((hipError_t)check_launch());
     }
-    for (int i = 1; i < kGauss; ++i) {
-      rc = launch_blur(g + (i - 1) * plane, ws + p.tmp_b, g + i * plane, W, H, sig[i], st);
+    for (int i = 1; i < kGauss; ++i) {  // Gaussian image i and the difference image i - 1 = G[i] - G[i - 1] in one pass
+      rc = launch_blur(g + (i - 1) * plane, ws + p.tmp_b, g + i * plane, W, H, sig[i], dg + (i - 1) * plane, st);
       if (rc) return rc;
     }
-    for (int i = 0; i < kDog; ++i) subtract_kernel<<<div_up(plane, kBlock), kBlock, 0, st>>>(g + (i + 1) * plane, g + i * plane, plane, dg + i * plane);
-    SIFT_TRY((hipError_t)check_launch());
     if (W > 2 * kBorder && H > 2 * kBorder) {
       const float thr = (float)floor(0.5 * kContrastThr / kLayers * 255.0);
       extrema_kernel<<<dim3(div_up(W - 2 * kBorder, kBlock), H - 2 * kBorder, kLayers), kBlock, 0, st>>>(dg, W, H, o, thr, cand, p.cand_cap, counters);
@@ -605,7 +635,7 @@ int sfm_sift_describe(const void* workspace, int32_t w, int32_t h, const float* 
   if (!workspace || w < 1 || h < 1 || n < 0 || (n > 0 && (!keypoints || !descriptors))) return SFM_EINVAL;
   if (n == 0) return 0;
   const Plan p = make_plan(w, h);
-  describe_kernel<<<div_up(n, 64), 64, 0, (hipStream_t)stream>>>((const float*)workspace, to_dev(p), keypoints, n, descriptors);
+  describe_kernel<<<div_up(n, 4), 64, 0, (hipStream_t)stream>>>((const float*)workspace, to_dev(p), keypoints, n, descriptors);
   return check_launch();
 }
 
