@@ -1,8 +1,8 @@
 """SIFT pair extraction with the reference's names (src/extract_sift.py).
 
 The feature front-end, next to the robust-estimation path: same function names and the same cache
-files as the reference.  SIFT detection needs cv2 (unless both cache files already exist next to
-the images, or the per-image features are cached); the descriptor matching runs on the GPU.
+files as the reference.  SIFT detection (sfm_hip/sift.py) and descriptor matching (sfm_hip/matching.py) run on
+the GPU; OpenCV is not needed.
 """
 from __future__ import annotations
 
@@ -14,8 +14,8 @@ from .utils import load_x_pairs, save_x_pairs
 
 
 def compute_sift_keypoints(image_path1, image_path2):
-    """Reference: src/extract_sift.py:88-135: SIFT on both images (OpenCV, once per image), 2-NN brute-force matching
-    on the GPU, ratio test 0.4; returns (x1 3xN, x2 3xN, descriptors of view 1 128xN)."""
+    """Reference: src/extract_sift.py:88-135: SIFT on both images (once per image), 2-NN brute-force matching, ratio
+    test 0.4, all on the GPU; returns (x1 3xN, x2 3xN, descriptors of view 1 128xN)."""
     from . import matching
 
     kp1, d1 = matching.image_features(image_path1, "bgr2gray")

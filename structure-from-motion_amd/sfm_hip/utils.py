@@ -1,9 +1,8 @@
 """Helpers with the names and signatures of the reference's src/utils.py.
 
 triangulate_3D_point_DLT runs on the GPU; the one-line array helpers are plain NumPy as in
-the reference.  find_correspondences belongs to the feature front-end: SIFT detection is OpenCV
-(raises if cv2 is not installed and the image's features are not cached), the brute-force
-2-nearest-neighbour matching runs on the GPU (sfm_hip/matching.py).
+the reference.  find_correspondences belongs to the feature front-end: SIFT detection (sfm_hip/sift.py) and the
+brute-force 2-nearest-neighbour matching (sfm_hip/matching.py) run on the GPU.
 """
 from __future__ import annotations
 
@@ -64,8 +63,8 @@ def skew_symmetric_mat(v):
 
 
 def find_correspondences(img_path, desc_X, X0, K):
-    """Reference: src/utils.py:65-93.  SIFT on one image (OpenCV, once per image), 2-NN brute-force match against the
-    stored descriptors on the GPU, ratio 0.75; returns (X float32 3xM, x_norm float64 3xM)."""
+    """Reference: src/utils.py:65-93.  SIFT on one image (once per image), 2-NN brute-force match against the stored
+    descriptors, ratio 0.75, all on the GPU; returns (X float32 3xM, x_norm float64 3xM)."""
     from . import matching
 
     kp, desc = matching.image_features(img_path, "grayscale")
