@@ -31,6 +31,9 @@ def process_sift_for_image_pairs(img_paths, init_pair, dataset):
     where = os.path.dirname(img_paths[0])
     x_pairs = load_x_pairs(x_pairs_file, where)
     if x_pairs is None:
+        from . import matching
+
+        matching.prefetch_images(img_paths, "bgr2gray")  # host threads decode the files while the GPU works on earlier ones
         x_pairs = []
         for i in range(len(img_paths) - 1):
             t0 = time.time()
