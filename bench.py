@@ -976,6 +976,14 @@ def main():
                 out["secondary"]["drop_in_replay"] = replay_throughput(torch, synthetic, orc, args.seed)
             except Exception as e:  # noqa: BLE001
                 out["secondary"] = {"error": f"{type(e).__name__}: {e}"}
+            try:  # the second half of the metric: end-to-end seconds on a dataset-5-shaped set of image files
+                import contextlib
+                import io
+
+                with contextlib.redirect_stderr(io.StringIO()):  # progress bars
+                    out["secondary"]["e2e_rendered_images"] = e2e_images(torch, synthetic, args.seed)
+            except Exception as e:  # noqa: BLE001
+                out["secondary"]["e2e_rendered_images"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
