@@ -108,3 +108,25 @@ def test_descriptors_match_across_a_rotation_and_scale_change(env):
     pred = np.stack([(pa[:, 0] * np.cos(ang) + pa[:, 1] * np.sin(ang)) * sc + c, (-pa[:, 0] * np.sin(ang) + pa[:, 1] * np.cos(ang)) * sc + c], axis=1)
     err = np.linalg.norm(pred - b.keypoints[ti], axis=1)
     assert np.median(err) < 1.0 and (err < 3.0).mean() > 0.8
+
+
+def test_degenerate_images_and_small_keypoint_buffers(env):
+    """Images smaller than the detector's border, a constant image, a one-pixel image: no keypoints and no fault; a
+    keypoint buffer that is too small is reported and the wrapper retries with a larger one."""
+    torch, C, sift = env
+    for shape in [(1, 1), (3, 50), (9, 12), (40, 7)]:
+        res = sift.detect_and_compute(np.full(shape, 77, np.uint8))
+        assert res.keypoints.shape == (0, 2) and res.descriptors.shape == (0, 128)
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 256, (9, 12)).astype(np.uint8)
+    res = sift.detect_and_compute(noise)
+    assert res.descriptors.shape[0] == res.keypoints.shape[0]
+    assert sift.detect_and_compute(np.full((64, 64), 200, np.uint8)).keypoints.shape[0] == 0
+    img = blob_image(120, 160, 70, 0)
+    full = sift.detect_and_compute(img)
+    small = sift.detect_and_compute(img, capacity=8)  # SFM_ETOOLARGE inside, then a second pass with room
+    assert full.keypoints.shape[0] > 8
+    np.testing.assert_array_equal(small.records, full.records)
+    np.testing.assert_array_equal(small.descriptors, full.descriptors)
+    with pytest.raises(ValueError):
+        sift.detect_and_compute(np.zeros((4, 4, 3), np.uint8))
