@@ -454,6 +454,38 @@ def e2e(torch, synthetic, orc, seed, with_cpu):
     return out
 
 
+def sift_full_size_vs_oracle(torch, synthetic, seed):
+    """One rendered 1936 x 1296 image through the GPU SIFT and through the NumPy restatement (about a minute on one core):
+    the CPU time beside the GPU time, and the comparison at full size."""
+    from oracle import sift as osift
+    from sfm_hip import sift
+
+    img = synthetic.render_views(n_cams=1, seed=seed)["images"][0]
+    g = torch.from_numpy(img).cuda()
+    sift.detect_and_compute(g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = sift.detect_and_compute(g)
+    torch.cuda.synchronize()
+    gpu_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    kps, (gauss, _) = osift.detect(img, taps_fn=sift.gaussian_taps)
+    desc = osift.describe(kps, gauss)
+    cpu_s = time.perf_counter() - t0
+    out = {"image": "1936 x 1296 rendered", "gpu_seconds": gpu_s, "cpu_oracle_seconds_one_core": cpu_s, "keypoints_gpu": int(res.records.shape[0]),
+           "keypoints_oracle": len(kps)}
+    if len(kps) == res.records.shape[0]:
+        ko = np.array([k[:5] for k in kps], np.float64)
+        out["positions_and_responses_identical"] = bool(np.array_equal(res.records[:, :2].astype(np.float64), ko[:, :2])
+                                                        and np.array_equal(res.records[:, 4].astype(np.float64), ko[:, 4]))
+        dang = np.abs(res.records[:, 3].astype(np.float64) - ko[:, 3])
+        out["max_angle_difference_degrees"] = float(np.minimum(dang, 360 - dang).max())
+        diff = np.abs(res.descriptors.astype(int) - desc.astype(int))
+        out["max_descriptor_difference"] = int(diff.max())
+        out["descriptor_entries_that_differ"] = float((diff != 0).mean())
+    return out
+
+
 def e2e_images(torch, synthetic, seed, n_cams=10, width=1936, height=1296):
     """The whole pipeline from image FILES, shaped like dataset 5 (10 images of 1936 x 1296, its intrinsics): rendered
     views of a textured two-plane scene are written as PNG files + cfg.yml, then the command-line driver's stages run:
@@ -664,13 +696,15 @@ def main():
     ap.add_argument("--e2e-cpu", action="store_true", help="with --e2e: also time the NumPy oracle end to end (minutes) and compare")
     ap.add_argument("--e2e-images", action="store_true",
                     help="only run the pipeline from rendered image files shaped like dataset 5 (SIFT + matching + geometry) and print it")
+    ap.add_argument("--sift-vs-oracle", action="store_true",
+                    help="only run one full-size image through the GPU SIFT and the NumPy restatement (about a minute) and print it")
     ap.add_argument("--sweep", action="store_true", help="only run the match-count sweep (2k..200k matches) and print it")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     workload = args.workload if args.workload != "auto" else ("c2" if world_env == 1 else "c5")
     all_cores = None
-    side_runs = args.e2e or args.sweep or args.e2e_images
+    side_runs = args.e2e or args.sweep or args.e2e_images or args.sift_vs_oracle
     if args.cpu_all_cores < 0:
         try:
             share = int(os.environ.get("OMP_NUM_THREADS", "0"))
@@ -706,6 +740,9 @@ def main():
 
     if args.e2e:
         print(json.dumps({"e2e": e2e(torch, synthetic, orc, args.seed, args.e2e_cpu)}))
+        return
+    if args.sift_vs_oracle:
+        print(json.dumps({"sift_vs_oracle": sift_full_size_vs_oracle(torch, synthetic, args.seed)}))
         return
     if args.e2e_images:
         print(json.dumps({"e2e_images": e2e_images(torch, synthetic, args.seed)}))
