@@ -122,6 +122,7 @@ int gaussian_taps(double sigma, Taps* t) {
 
 // BORDER_REFLECT_101 for any offset (the last octaves are smaller than the kernels)
 __device__ __forceinline__ int reflect101(int i, int n) {
+  if ((unsigned)i < (unsigned)n) return i;  // interior: no division
   if (n == 1) return 0;
   const int p = 2 * (n - 1);
   i %= p;
@@ -157,7 +158,43 @@ __global__ __launch_bounds__(kBlock) void blur_rows_kernel(const float* __restri
 // one workgroup = a tile of 64 columns x 64 rows staged in LDS with the reflected margins above and below; a thread
 // owns one column and 16 consecutive rows.  When `prev` is given (the Gaussian image this blur started from) the
 // difference image new - prev is written as well.
+// Two forms: the windowed one (kernels of up to 27 taps, every kernel of the default scale space) pads the taps with
+// zeros to 27 around the centre and keeps a thread's 16 + 26 input values in registers, so that each staged value is
+// read from LDS once instead of once per tap (a zero tap adds +-0: the sums are those of the unpadded kernel bit for
+// bit); the generic one reads LDS once per tap and takes any kernel size.
 constexpr int kColTile = 64;
+constexpr int kWinR = 13, kWinTaps = 2 * kWinR + 1;
+__global__ __launch_bounds__(kBlock) void blur_cols_window_kernel(const float* __restrict__ src, int w, int h, Taps taps, float* __restrict__ dst,
+                                                                  const float* __restrict__ prev, float* __restrict__ diff) {
+  __shared__ float tile[kColTile + 2 * kWinR][kColTile];
+  const int x0 = blockIdx.x * kColTile, y0 = blockIdx.y * kColTile;
+  const int cx = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int x = x0 + cx;
+  const int xs = min(x, w - 1);
+  for (int i = part; i < kColTile + 2 * kWinR; i += kBlock / 64) tile[i][cx] = src[(long long)reflect101(y0 + i - kWinR, h) * w + xs];
+  __syncthreads();
+  if (x >= w) return;
+  const int pad = kWinR - (taps.n - 1) / 2;  // zero taps on either side
+  float win[16 + 2 * kWinR];
+#pragma unroll
+  for (int j = 0; j < 16 + 2 * kWinR; ++j) win[j] = tile[part * 16 + j][cx];
+  float k[kWinTaps];
+#pragma unroll
+  for (int t = 0; t < kWinTaps; ++t) k[t] = (t >= pad && t < pad + taps.n) ? taps.k[t - pad] : 0.0f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int y = y0 + part * 16 + j;
+    float acc = win[j] * k[0];
+#pragma unroll
+    for (int t = 1; t < kWinTaps; ++t) acc = acc + win[j + t] * k[t];
+    if (y < h) {
+      const long long p = (long long)y * w + x;
+      dst[p] = acc;
+      if (diff) diff[p] = acc - prev[p];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void blur_cols_kernel(const float* __restrict__ src, int w, int h, Taps taps, float* __restrict__ dst,
                                                            const float* __restrict__ prev, float* __restrict__ diff) {
   __shared__ float tile[kColTile + kMaxTaps][kColTile];
@@ -535,7 +572,11 @@ int launch_blur(const float* src, float* tmp, float* dst, int w, int h, double s
   const int rc = gaussian_taps(sigma, &taps);
   if (rc) return rc;
   blur_rows_kernel<<<dim3(div_up(w, kBlock), h), kBlock, 0, st>>>(src, w, h, taps, tmp);
-  blur_cols_kernel<<<dim3(div_up(w, kColTile), div_up(h, kColTile)), kBlock, 0, st>>>(tmp, w, h, taps, dst, diff ? src : nullptr, diff);
+  const dim3 grid(div_up(w, kColTile), div_up(h, kColTile));
+  if (taps.n <= kWinTaps)
+    blur_cols_window_kernel<<<grid, kBlock, 0, st>>>(tmp, w, h, taps, dst, diff ? src : nullptr, diff);
+  else
+    blur_cols_kernel<<<grid, kBlock, 0, st>>>(tmp, w, h, taps, dst, diff ? src : nullptr, diff);
   return check_launch();
 }
 
