@@ -18,8 +18,10 @@ def compute_sift_keypoints(image_path1, image_path2):
     test 0.4, all on the GPU; returns (x1 3xN, x2 3xN, descriptors of view 1 128xN)."""
     from . import matching
 
-    kp1, d1 = matching.image_features(image_path1, "bgr2gray")
-    kp2, d2 = matching.image_features(image_path2, "bgr2gray")
+    kp1, _ = matching.image_features(image_path1, "bgr2gray")
+    kp2, _ = matching.image_features(image_path2, "bgr2gray")
+    d1 = matching.image_descriptor_set(image_path1, "bgr2gray")
+    d2 = matching.image_descriptor_set(image_path2, "bgr2gray")
     return matching.match_keypoints(kp1, d1, kp2, d2, ratio=0.4)
 
 

@@ -30,6 +30,7 @@ class DescriptorSet:
         if d.dtype != np.uint8:
             d = np.ascontiguousarray(d, dtype=np.float32)
         self.n = d.shape[0]
+        self.host = d  # the descriptors as given (match_keypoints returns the matched ones)
         self.d8, self.norm = ops.descriptors_to_i8(torch.from_numpy(np.ascontiguousarray(d)).cuda())
 
 
@@ -128,14 +129,31 @@ def detect_features(img_path, mode):
     return res.keypoints, res.descriptors
 
 
+_sets = {}
+
+
+def image_descriptor_set(img_path, mode):
+    """The descriptors of image_features(img_path, mode) resident on the GPU in the matcher's layout, built once per image
+    (an image is matched several times: against both neighbours, and against the reconstructed points in two stages)."""
+    kp, desc = image_features(img_path, mode)
+    hit = _sets.get(id(desc))
+    if hit is None or hit[0] is not desc:
+        if len(_sets) > 4096:
+            _sets.clear()
+        hit = _sets[id(desc)] = (desc, DescriptorSet(desc) if desc.shape[0] else None)
+    return hit[1] if hit[1] is not None else desc
+
+
 def match_keypoints(kp1, desc1, kp2, desc2, ratio=0.4):
     """The array part of compute_sift_keypoints (src/extract_sift.py:116-135): returns
-    (x1 3xN float64 homogeneous, x2 3xN, descriptors of view 1 128xN float32) for the good matches."""
+    (x1 3xN float64 homogeneous, x2 3xN, descriptors of view 1 128xN float32) for the good matches.  desc1, desc2: [n][128]
+    arrays or DescriptorSets."""
     qi, ti, _ = knn_match_ratio(desc1, desc2, ratio)
     one = np.ones((1, qi.size))
     x1 = np.vstack((np.float32(kp1[qi]).T.reshape(2, -1), one))
     x2 = np.vstack((np.float32(kp2[ti]).T.reshape(2, -1), one))
-    return x1, x2, np.asarray(desc1)[qi].astype(np.float32).T
+    host1 = desc1.host if isinstance(desc1, DescriptorSet) else np.asarray(desc1)
+    return x1, x2, host1[qi].astype(np.float32).T
 
 
 def correspondences_from_features(kp, desc, desc_X, X0, K, ratio=0.75):

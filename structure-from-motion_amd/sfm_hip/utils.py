@@ -67,8 +67,8 @@ def find_correspondences(img_path, desc_X, X0, K):
     descriptors, ratio 0.75, all on the GPU; returns (X float32 3xM, x_norm float64 3xM)."""
     from . import matching
 
-    kp, desc = matching.image_features(img_path, "grayscale")
-    return matching.correspondences_from_features(kp, desc, desc_X, X0, K, ratio=0.75)
+    kp, _ = matching.image_features(img_path, "grayscale")
+    return matching.correspondences_from_features(kp, matching.image_descriptor_set(img_path, "grayscale"), desc_X, X0, K, ratio=0.75)
 
 
 def log_execution_time(func):
