@@ -98,7 +98,12 @@ class _Decoder:
         if self.pool is None:
             from concurrent.futures import ThreadPoolExecutor
 
-            self.pool = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) - 1)))
+            try:  # this job's share of the host cores, where the launcher states it
+                share = int(os.environ.get("OMP_NUM_THREADS", "0"))
+            except ValueError:
+                share = 0
+            cores = share if share > 0 else (os.cpu_count() or 2) - 1
+            self.pool = ThreadPoolExecutor(max_workers=max(1, min(16, cores)))
         for k in self.order[i : i + self.AHEAD]:
             if k not in self.futures:
                 self.futures[k] = self.pool.submit(sift.read_gray, k[0], k[1])
