@@ -63,8 +63,8 @@ def _fast_path_ok():
     return _checked
 
 
-def _fill(st, bg, n, count):
-    out = np.empty(int(count), np.int32)
+def _fill(st, bg, n, count, out=None):
+    out = np.empty(int(count), np.int32) if out is None else out
     with bg.lock:
         pos = ctypes.c_int32(st.pos)
         C.check(C.load_library().sfm_legacy_randint_fill(ctypes.addressof(st.key), ctypes.byref(pos), int(n), int(count), C.hptr(out)))
@@ -72,12 +72,19 @@ def _fill(st, bg, n, count):
     return out
 
 
-def randint(n, count):
-    """np.random.randint(0, n, size=count) as int32, consuming the global legacy stream identically."""
+def randint(n, count, out=None):
+    """np.random.randint(0, n, size=count) as int32, consuming the global legacy stream identically.  `out`: an optional
+    contiguous int32 array of `count` elements to fill instead of a new one (page-locked memory, for instance)."""
+    if out is not None and (out.dtype != np.int32 or out.size != count or not out.flags.c_contiguous):
+        raise ValueError("out must be a contiguous int32 array of `count` elements")
     if count > 0 and 0 < n < 2**31 and _fast_path_ok():
         st, bg = _global_state()
-        return _fill(st, bg, n, count)
-    return np.random.randint(0, n, size=count).astype(np.int32)
+        return _fill(st, bg, n, count, out)
+    drawn = np.random.randint(0, n, size=count).astype(np.int32)
+    if out is None:
+        return drawn
+    out[...] = drawn.reshape(out.shape)
+    return out
 
 
 def mark():

@@ -71,3 +71,21 @@ def test_bad_arguments_are_rejected():
     pos = ctypes.c_int32(0)
     assert lib.sfm_legacy_randint_fill(C.hptr(key), ctypes.byref(pos), 0, 4, C.hptr(out)) == 100001
     assert lib.sfm_legacy_randint_fill(C.hptr(key), ctypes.byref(pos), 2**31, 4, C.hptr(out)) == 100001
+
+
+def test_randint_fills_a_caller_buffer_identically():
+    from sfm_hip import legacy_rng
+
+    np.random.seed(77)
+    want = np.random.randint(0, 4321, size=5000)
+    after = np.random.randint(0, 1 << 30, 3)
+    np.random.seed(77)
+    buf = np.empty(5000, np.int32)
+    got = legacy_rng.randint(4321, 5000, out=buf)
+    assert got is buf
+    np.testing.assert_array_equal(buf, want)
+    np.testing.assert_array_equal(np.random.randint(0, 1 << 30, 3), after)
+    with pytest.raises(ValueError):
+        legacy_rng.randint(10, 7, out=np.empty(8, np.int32))
+    with pytest.raises(ValueError):
+        legacy_rng.randint(10, 8, out=np.empty(8, np.int64))

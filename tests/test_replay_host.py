@@ -147,8 +147,12 @@ class AsyncOracleBackend(BoundedOracleBackend):
         self.submitted = getattr(self, "submitted", 0) + 1
         return (idx, best_E > 0 and best_H > 0)
 
+    def discard(self, handle):
+        self.discarded = getattr(self, "discarded", 0) + 1
+
     def collect(self, handle, best_E, best_H):
         idx, bounded = handle
+        self.collected = getattr(self, "collected", 0) + 1
         if bounded:
             return self.score_bounded(idx, best_E, best_H)
         return self.score(idx) + (None,)
@@ -165,6 +169,7 @@ def test_draw_ahead_replay_reproduces_reference_runs(golden, tag, chunk0, chunk_
     be = AsyncOracleBackend(x1, x2, 1.0 / sc["K"][0][0])
     st = run_replay(int(n), be, chunk0=chunk0, chunk_max=chunk_max)
     assert be.submitted > 0
+    assert be.submitted == be.collected + getattr(be, "discarded", 0)  # every block in flight is collected or waited for
     assert st.it == len(g[f"{tag}_cH"])
     np.testing.assert_allclose(st.R, g[f"{tag}_R"], atol=1e-9)
     np.testing.assert_allclose(np.reshape(st.T, (3, 1)), g[f"{tag}_T"], atol=1e-9)
