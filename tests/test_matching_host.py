@@ -93,3 +93,29 @@ def test_matcher_refuses_to_run_without_gpu(fake_cv2):
 
     with pytest.raises(_capi.SfmHipError):
         matching.DescriptorSet(np.zeros((4, 128), np.uint8))
+
+
+def test_read_gray_without_opencv_handles_colour_and_gray_files(tmp_path, monkeypatch):
+    """Without cv2 the image files are decoded with Pillow: colour files become ITU-R 601 luma (the weights of
+    cv2.COLOR_BGR2GRAY and of IMREAD_GRAYSCALE), gray files are taken as they are, both read modes give the same array."""
+    from PIL import Image
+
+    from sfm_hip import sift
+
+    monkeypatch.setitem(sys.modules, "cv2", None)  # importing cv2 raises ImportError
+    rng = np.random.default_rng(0)
+    rgb = rng.integers(0, 256, (20, 30, 3)).astype(np.uint8)
+    gray = rng.integers(0, 256, (20, 30)).astype(np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "c.png")
+    Image.fromarray(gray).save(tmp_path / "g.png")
+    Image.fromarray(rgb).save(tmp_path / "c.jpg", quality=95)
+    a = sift.read_gray(str(tmp_path / "c.png"), "bgr2gray")
+    b = sift.read_gray(str(tmp_path / "c.png"), "grayscale")
+    assert a.dtype == np.uint8 and a.shape == (20, 30) and (a == b).all()
+    f = rgb.astype(float)
+    luma = (f[..., 0] * 299 + f[..., 1] * 587 + f[..., 2] * 114) / 1000.0
+    assert np.abs(a.astype(float) - luma).max() <= 1.0
+    assert (sift.read_gray(str(tmp_path / "g.png"), "grayscale") == gray).all()
+    assert sift.read_gray(str(tmp_path / "c.jpg"), "bgr2gray").shape == (20, 30)
+    with pytest.raises(ValueError):
+        sift.read_gray(str(tmp_path / "c.png"), "other")
