@@ -26,16 +26,38 @@ class SiftResult:
         self.descriptors = descriptors
 
 
+def _full_order(raw, rows):
+    """OpenCV's keypoint order of the given rows: (x, y, size desc, angle, response desc, octave desc, input position)."""
+    r = raw[rows]
+    octave = r[:, 5].view(np.int32).astype(np.int64)
+    return rows[np.lexsort((rows, -octave, -r[:, 4].astype(np.float64), r[:, 3], -r[:, 2].astype(np.float64), r[:, 1], r[:, 0]))]
+
+
 def _sort_and_dedupe(raw):
     """KeyPointsFilter::removeDuplicatedSorted: order by (x, y, size desc, angle, response desc, octave desc), then
     keep the first of every run with equal (x, y, size, angle)."""
-    if raw.shape[0] == 0:
+    n = raw.shape[0]
+    if n == 0:
         return raw
-    octave = raw[:, 5].view(np.int32).astype(np.int64)
-    order = np.lexsort((np.arange(raw.shape[0]), -octave, -raw[:, 4].astype(np.float64), raw[:, 3], -raw[:, 2].astype(np.float64),
-                        raw[:, 1], raw[:, 0]))
+    xy = np.ascontiguousarray(raw[:, :2])
+    if np.all(xy >= 0):
+        # non-negative float32 order like their bit patterns: one sort on a 64-bit (x, y) key, then only the runs that
+        # share a position (a keypoint with several orientations) need the remaining keys
+        bits = xy.view(np.uint32).astype(np.uint64)
+        key = (bits[:, 0] << np.uint64(32)) | bits[:, 1]
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        tied = np.zeros(n, bool)
+        same = ks[1:] == ks[:-1]
+        tied[1:] |= same
+        tied[:-1] |= same
+        if tied.any():
+            pos = np.flatnonzero(tied)
+            order[pos] = _full_order(raw, order[pos])  # runs stay where they are: the (x, y) key is their leading key
+    else:
+        order = _full_order(raw, np.arange(n))
     s = raw[order]
-    keep = np.ones(s.shape[0], bool)
+    keep = np.ones(n, bool)
     keep[1:] = np.any(s[1:, :4] != s[:-1, :4], axis=1)
     return s[keep]
 
