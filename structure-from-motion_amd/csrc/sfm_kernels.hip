@@ -2102,7 +2102,9 @@ static int run_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx,
   SFM_TRY(hipMemsetAsync(xy + npad, 0, 16, st));  // trailer: measured max |coordinate|
   corr_to_mfma2_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, pieces, xy);
   SFM_TRY(check_launch());
-  static const int split_models = getenv("SFM_HIP_EHX_SPLIT") ? atoi(getenv("SFM_HIP_EHX_SPLIT")) : 0;
+  // two launches (one model each, at a higher occupancy) pay from about 2^28 pairs on; below that the second launch costs more
+  static const int split_env = getenv("SFM_HIP_EHX_SPLIT") ? atoi(getenv("SFM_HIP_EHX_SPLIT")) : -1;
+  const bool split_models = split_env >= 0 ? split_env != 0 : (long long)nb * n >= (1LL << 28);
   const dim3 grid((unsigned)tiles, splits);
   if (split_models) {
     eh_score_mfma_kernel<true, false, 3><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e, thr_h * thr_h,
