@@ -979,6 +979,9 @@ def main():
                                    "cores + float32, float64 inside the error bands; evaluates the reference's tests for every pair)",
                                    "kernel_ms": mixed_ms, "achieved": flops_per_launch / (mixed_ms * 1e-3) / 1e12, "peak": PEAK_FP32_VALU_TFLOPS,
                                    "unit": "TFLOP/s", "frac": flops_per_launch / (mixed_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                                   "evals_per_s": 2.0 * B * n / (mixed_ms * 1e-3),
+                                   "evals_note": "the rate at which the reference's own residual tests are decided for EVERY (hypothesis, match) pair; "
+                                                 "`value` above counts pairs that went through the bound tests instead",
                                    "counts_identical_to_f64_kernel": mixed_identical, "issue": exact},
             "f64_kernel": {"kernel": "eh_score_kernel (every test in float64)", "kernel_ms": f64_ms,
                            "achieved": flops_per_launch / (f64_ms * 1e-3) / 1e12, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
