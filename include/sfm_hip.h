@@ -120,7 +120,11 @@ int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_
  * allocating call inside.  It has no counterpart in the reference.  The match-side operands (72 bytes per match) go into
  * a fixed array inside the library, SFM_NOALLOC_MAX_MATCHES * 72 bytes (2.25 MiB) that every GPU the library runs on
  * holds until the process ends; n beyond that capacity is rejected with SFM_ETOOLARGE.  All calls on one GPU share
- * that array: calls that overlap on one GPU (different streams or threads) race; calls on one stream are safe. */
+ * that array: calls that overlap on one GPU (different streams or threads) race; calls on one stream are safe.
+ * The array used is the one of the GPU that owns `stream` (of the current GPU for a NULL stream); the kernels are
+ * launched on `stream`, so it should belong to the current device like the data pointers.  The first call on a GPU
+ * looks up the array's address there (which may load the library's code object): make one call per GPU outside graph
+ * capture before capturing one. */
 #define SFM_NOALLOC_MAX_MATCHES 32768
 int sfm_eh_score_noalloc(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
                          int32_t* count_e, int32_t* count_h, void* stream);

@@ -3,8 +3,10 @@
 
 OpenCV is a third-party dependency of the reference (opencv-python, not vendored, not importable here), so this file
 restates the published algorithm of its features2d module (sift.dispatch.cpp / sift.simd.hpp of OpenCV 4.5+: Lowe's
-SIFT with a doubled base image, 3 layers per octave, sigma 1.6, contrast threshold 0.04, edge threshold 10, float
-pyramid, descriptors scaled by 512 and saturated to [0, 255]).  PARITY UNPINNED: the reference holds no keypoint or
+SIFT with a base image doubled by INTER_LINEAR resize (the default, enable_precise_upscale = False), 3 layers per octave,
+sigma 1.6, contrast threshold 0.04, edge threshold 10, float pyramid, descriptors scaled by 512 and saturated to [0, 255];
+taps are summed in ascending order and the first blur's sigma is computed in double, where OpenCV pairs symmetric taps and
+uses float32, so the pyramid may differ from OpenCV's in the last place).  PARITY UNPINNED: the reference holds no keypoint or
 descriptor fixtures and OpenCV cannot be run here, so nothing ties this restatement to cv2's output bit for bit; what is
 pinned is that the HIP implementation equals this restatement (tests/test_gpu_sift.py) and that both behave like SIFT
 (blobs found at their scale, matches across a rotation and a scale change; tests/test_sift_host.py).
@@ -78,14 +80,23 @@ def _reflect_many(i, n):
 
 
 def upsample2x(gray_u8):
-    """dst(x, y) = bilinear sample of src at (x / 2, y / 2), BORDER_REFLECT (createInitialImage of OpenCV 4.5+)."""
+    """cv::resize(src, 2 x size, INTER_LINEAR), the branch createInitialImage takes for SIFT_create()'s default
+    enable_precise_upscale = False: pixel centres aligned, dst(X) samples src at X / 2 - 0.25 with the border replicated,
+    i.e. even X = 2m -> 0.25 src[m-1] + 0.75 src[m], odd X = 2m+1 -> 0.75 src[m] + 0.25 src[m+1]; rows first, then
+    columns (every product and sum is exact in float32)."""
     src = gray_u8.astype(F)
     h, w = src.shape
 
     def axis(a, n, ax):
-        i0 = np.arange(2 * n) // 2
-        i1 = np.minimum(i0 + (np.arange(2 * n) % 2), n - 1)  # BORDER_REFLECT: index n -> n - 1
-        return (np.take(a, i0, axis=ax) * F(0.5) + np.take(a, i1, axis=ax) * F(0.5)).astype(F)
+        X = np.arange(2 * n)
+        m, odd = X // 2, (X % 2).astype(bool)
+        i0 = np.where(odd, m, np.maximum(m - 1, 0))
+        i1 = np.where(odd, np.minimum(m + 1, n - 1), m)
+        w0 = np.where(odd, F(0.75), F(0.25)).astype(F)
+        w1 = (F(1.0) - w0).astype(F)
+        shape = [1, 1]
+        shape[ax] = 2 * n
+        return (np.take(a, i0, axis=ax) * w0.reshape(shape) + np.take(a, i1, axis=ax) * w1.reshape(shape)).astype(F)
 
     return axis(axis(src, w, 1), h, 0)
 

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "../../include/sfm_hip.h"
 #include "sfm_math.hpp"
@@ -24,6 +25,41 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kMaxCams = 64;
+
+// Diagnostic build only (-DSFM_CLOCK_STAMPS, never the shipped library): wave 0..3 of every workgroup of the three
+// matrix-core kernels stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around its tile loop into a buffer
+// of its own that no kernel reads; sfm_debug_clock_stamps copies it out.  held clock = cycles / ticks x 100 MHz.
+// A record is 8 x uint64: cycles, ticks, tiles walked, start tick, end tick, (XCC_ID << 32) | HW_ID of the wave, the tick at
+// which the wave entered the kernel, 0.
+#ifdef SFM_CLOCK_STAMPS
+constexpr int kStampSlots = 16384;
+__device__ unsigned long long g_stamps[kStampSlots * 8];
+#define SFM_STAMP_ENTRY() const unsigned long long stamp_entry_ = __builtin_amdgcn_s_memrealtime()
+#define SFM_STAMP_BEGIN()                                                   \
+  const unsigned long long stamp_r0_ = __builtin_amdgcn_s_memrealtime(); \
+  const unsigned long long stamp_t0_ = __builtin_amdgcn_s_memtime()
+#define SFM_STAMP_END(units)                                                                                                    \
+  do {                                                                                                                          \
+    const unsigned long long stamp_t1_ = __builtin_amdgcn_s_memtime();                                                          \
+    const unsigned long long stamp_r1_ = __builtin_amdgcn_s_memrealtime();                                                      \
+    if ((threadIdx.x & 63) == 0) {                                                                                              \
+      const unsigned long long wg_ = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + (unsigned long long)gridDim.y * blockIdx.z); \
+      unsigned long long* dst_ = g_stamps + 8 * ((wg_ * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kStampSlots);                 \
+      dst_[0] = stamp_t1_ - stamp_t0_;                                                                                          \
+      dst_[1] = stamp_r1_ - stamp_r0_;                                                                                          \
+      dst_[2] = (unsigned long long)(units);                                                                                    \
+      dst_[3] = stamp_r0_;                                                                                                      \
+      dst_[4] = stamp_r1_;                                                                                                      \
+      dst_[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4); \
+      dst_[6] = stamp_entry_;                                                                                                   \
+      dst_[7] = 0;                                                                                                              \
+    }                                                                                                                           \
+  } while (0)
+#else
+#define SFM_STAMP_ENTRY() do { } while (0)
+#define SFM_STAMP_BEGIN() do { } while (0)
+#define SFM_STAMP_END(units) do { } while (0)
+#endif
 
 struct CamOffsets {
   int64_t off[kMaxCams + 1];
@@ -434,14 +470,41 @@ __device__ __forceinline__ float min3_abs(float m, float a, float b) {
   return r;
 }
 
-template <bool kDoE, bool kDoH>
-__global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
+// kFloatCount: test outcomes are produced as 0.0f / 1.0f by the output clamp of the test's last instruction and summed
+// with float adds (both full-rate instructions; v_alignbit_b32, like v_min/v_max/v_add3/v_cmp, issues at half rate on
+// gfx950: profiles/microbench/valu_issue_probe).  For that the models are scaled by 2^40 (E) and 2^44 (H) on top of the
+// uniform-band scaling, which shifts exponents only: a test value is then zero, negative, or at least 1 in magnitude
+// (the constants c' 2^80 >= 2^50 and g' 2^44 >= 2^26 put every float that can cancel against them on a grid coarser
+// than 1), so clamp(value) is exactly 1 for a pass and 0 otherwise.  The launcher selects this form only for thresholds
+// with 2^-45 < k1 < 0.6, where neither the squares (<= 0.7 / k1 and (0.84 / xmax)^2, times 2^80) can overflow nor c'
+// fall below 2^-30; the sign-history form serves every other threshold.
+constexpr double kLambdaE = 0x1.0p40, kLambdaH = 0x1.0p44;
+
+// clamp(c - a a) and clamp(b - |a|) to [0, 1], each ONE full-rate instruction: the clamp is the output modifier of the
+// fma / subtraction itself (a NaN becomes 0: kernels run with DX10_CLAMP set)
+__device__ __forceinline__ float clamp01_c_minus_sq(float a, float c) {
+  float r;
+  asm("v_fma_f32 %0, -%1, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float clamp01_b_minus_abs(float b, float a) {
+  float r;
+  asm("v_sub_f32_e64 %0, %1, |%2| clamp" : "=v"(r) : "v"(b), "v"(a));
+  return r;
+}
+
+template <bool kDoE, bool kDoH, bool kFloatCount>
+__global__ __launch_bounds__(kBlock, 3) void eh_upper_mfma_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
                                                                   const float2* __restrict__ xy, int n, const int32_t* __restrict__ idx,
                                                                   long long nb, double two_thr_e2, double thr_h2, double xmax, double safety,
                                                                   int* __restrict__ up_e, int* __restrict__ up_h, int tiles_per_split,
                                                                   int use_atomics) {
   __shared__ unsigned char fin[kBlock / 64][64];
   __shared__ uint4 bstage[kBlock / 64][64][6][2];
+  SFM_STAMP_ENTRY();
+  // the solve is a long serial chain per wave: it runs ahead of the other waves' tile loops (which saturate the vector
+  // issue and would starve it otherwise), so that all resident waves are inside their tile loops most of the time
+  __builtin_amdgcn_s_setprio(3);
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long hyp = gid < nb ? gid : nb - 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -478,6 +541,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
       const double eL = (kEpsMfma + 2.0 * kEps32) * (R0 + R1);
       const double G = safety * (Es + sqrt(two_thr_e2) * eL);
       inv *= kGe / G;  // now this model's G is kGe (G > 0: the unit-scaled model has an entry of magnitude 1)
+      if constexpr (kFloatCount) inv *= kLambdaE;
     }
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
@@ -491,6 +555,7 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
       const double Dx = (kEpsMfma + 3.0 * kEps32) * (R0 + xm * R2), Dy = (kEpsMfma + 3.0 * kEps32) * (R1 + xm * R2);
       const double G = safety * (sqrt(thr_h2) * ez + Dx + Dy);
       inv *= kGh / G;
+      if constexpr (kFloatCount) inv *= kLambdaH;
     }
 #pragma unroll
     for (int v = 0; v < 3; ++v) {
@@ -505,9 +570,10 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
 #pragma unroll
     for (int v = 0; v < 6; ++v) B[k][v] = as_bf16x8(bstage[wave][32 * k + col][v][half]);
   // c' = G^2 (1 + 1/mu) / k1, rt' = sqrt(T) / sqrt(k1), g' = G / sqrt(k1), each rounded up with room for the float32 roundings
-  const float cprime = round_up_f32(kGe * kGe * (1.0 + 1.0 / kMuE) * inv_sqrt_k1 * inv_sqrt_k1 * (1.0 + 32.0 * kEps32));
+  const float cprime = round_up_f32(kGe * kGe * (1.0 + 1.0 / kMuE) * inv_sqrt_k1 * inv_sqrt_k1 * (1.0 + 32.0 * kEps32)) *
+                       (kFloatCount ? (float)(kLambdaE * kLambdaE) : 1.0f);  // the scale factors are powers of two: exact
   const float rtp = round_up_f32(sqrt(thr_h2) * inv_sqrt_k1 * (1.0 + 16.0 * kEps32));
-  const float gp = round_up_f32(kGh * inv_sqrt_k1 * (1.0 + 16.0 * kEps32));
+  const float gp = round_up_f32(kGh * inv_sqrt_k1 * (1.0 + 16.0 * kEps32)) * (kFloatCount ? (float)kLambdaH : 1.0f);
   // accumulator register i of a lane in half h is matrix row (i&3) + 8(i>>2) + 4h; the A row that
   // lane `col` supplies is loaded from the match whose position in the tile is 16h' + i for that row,
   // so that half h scores the 16 consecutive matches 16h .. 16h+15 of the tile
@@ -516,54 +582,101 @@ __global__ __launch_bounds__(kBlock, 2) void eh_upper_mfma_kernel(const double4*
   const int t0 = blockIdx.y * tiles_per_split;
   const int t1 = min(ntiles, t0 + tiles_per_split);
   int ce[2] = {0, 0}, ch[2] = {0, 0};
-  unsigned he[2] = {0, 0}, hh[2] = {0, 0};  // sign-bit histories: one v_alignbit per test instead of compare + add-with-carry
+  unsigned he[2] = {0, 0}, hh[2] = {0, 0};  // sign-bit histories (kFloatCount = false): one v_alignbit per test
+  float fe[2] = {0.0f, 0.0f}, fh[2] = {0.0f, 0.0f};  // float counts (kFloatCount = true): exact integers below 2^24
   const f32x16 zero = {0};
   // bit 15-i of a history is match 16*half + i of a tile; only tile n/32 (when n is not a multiple of 32) has padding to mask out
   const unsigned tail_mask = tile_tail_mask(n, half);
   const uint4* asrc = pieces + 2 * (t0 * 32 + apos) + half;
   const float4* xsrc = reinterpret_cast<const float4*>(xy + t0 * 32 + 16 * half);
-  for (int t = t0; t < t1; ++t, asrc += 64, xsrc += 16) {
-    const bf16x8 A = as_bf16x8(*asrc);
-    const unsigned vmask = t == (n >> 5) ? tail_mask : 0xFFFFu;
-    float x2[16], y2[16];
-    {
-      const float4* q = xsrc;
+  // Match-side operands of the current tile: loaded one tile ahead.  The loads of tile t + 1 are issued inside the last
+  // of the four test blocks of tile t, each into the register its last reader has just released (A after the block's
+  // MFMAs, (x2, y2) pair by pair), so a wave meets no load latency at the top of a tile: with three waves per SIMD, whose
+  // combined issue rate barely exceeds what the SIMD can take, every stall of a wave is lost issue time.
+  bf16x8 A = as_bf16x8(*asrc);
+  float x2[16], y2[16];
+  auto load_xy = [&](const float4* q, int pair) {
+    const float4 v = q[pair];
+    x2[2 * pair] = v.x; y2[2 * pair] = v.y; x2[2 * pair + 1] = v.z; y2[2 * pair + 1] = v.w;
+  };
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float4 v = q[i];
-        x2[2 * i] = v.x; y2[2 * i] = v.y; x2[2 * i + 1] = v.z; y2[2 * i + 1] = v.w;
-      }
-    }
+  for (int i = 0; i < 8; ++i) load_xy(xsrc, i);
+  // one tile of 32 matches against the wave's 64 hypotheses; kMasked: the tile with padding (float counts are weighted
+  // with the 0/1 mask of its real matches, at the same instruction count); anext / xnext: where the next tile's operands are
+  auto score_tile = [&](auto masked_tag, const uint4* anext, const float4* xnext) {
+    constexpr bool kMasked = decltype(masked_tag)::value;
+    constexpr bool kLastE = kDoE && !kDoH;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if constexpr (kDoE) {
         const f32x16 l0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][0], zero, 0, 0, 0);
         const f32x16 l1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][1], zero, 0, 0, 0);
         const f32x16 l2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][2], zero, 0, 0, 0);
+        if (kLastE && k == 1) A = as_bf16x8(*anext);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float s = fma(l0[i], x2[i], fma(l1[i], y2[i], l2[i]));  // s / sqrt(k1)
-          const float d = fma(s, s, fma(-l1[i], l1[i], fma(-l0[i], l0[i], -cprime)));  // inlier (or within the slack) <=> d < 0
-          he[k] = __builtin_amdgcn_alignbit(he[k], __float_as_uint(d), 31);  // shift the sign bit into the history
+          if (kLastE && k == 1 && (i & 1)) load_xy(xnext, i >> 1);
+          if constexpr (kFloatCount) {
+            const float t = clamp01_c_minus_sq(s, fma(l1[i], l1[i], fma(l0[i], l0[i], cprime)));  // 1 <=> inlier (or within the slack)
+            if constexpr (kMasked)
+              fe[k] = fma(t, ((tail_mask >> (15 - i)) & 1u) ? 1.0f : 0.0f, fe[k]);
+            else
+              fe[k] += t;
+          } else {
+            const float d = fma(s, s, fma(-l1[i], l1[i], fma(-l0[i], l0[i], -cprime)));  // inlier (or within the slack) <=> d < 0
+            he[k] = __builtin_amdgcn_alignbit(he[k], __float_as_uint(d), 31);  // shift the sign bit into the history
+          }
         }
-        ce[k] += __popc(he[k] & vmask);
+        if constexpr (!kFloatCount) ce[k] += __popc(he[k] & (kMasked ? tail_mask : 0xFFFFu));
       }
       if constexpr (kDoH) {
         const f32x16 hx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][3], zero, 0, 0, 0);
         const f32x16 hy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][4], zero, 0, 0, 0);
         const f32x16 hz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[k][5], zero, 0, 0, 0);
+        if (k == 1) A = as_bf16x8(*anext);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float dx = fma(x2[i], hz[i], -hx[i]);
           const float dy = fma(y2[i], hz[i], -hy[i]);
+          if (k == 1 && (i & 1)) load_xy(xnext, i >> 1);
           const float lim = fma(rtp, fabsf(hz[i]), gp);
-          const float d = fmaxf(fabsf(dx), fabsf(dy)) - lim;
-          hh[k] = __builtin_amdgcn_alignbit(hh[k], __float_as_uint(d), 31);
+          if constexpr (kFloatCount) {
+            const float tx = clamp01_b_minus_abs(lim, dx), ty = clamp01_b_minus_abs(lim, dy);  // both 1 <=> inside the box
+            if constexpr (kMasked)
+              fh[k] = fma(tx * ty, ((tail_mask >> (15 - i)) & 1u) ? 1.0f : 0.0f, fh[k]);
+            else
+              fh[k] = fma(tx, ty, fh[k]);
+          } else {
+            const float d = fmaxf(fabsf(dx), fabsf(dy)) - lim;
+            hh[k] = __builtin_amdgcn_alignbit(hh[k], __float_as_uint(d), 31);
+          }
         }
-        ch[k] += __popc(hh[k] & vmask);
+        if constexpr (!kFloatCount) ch[k] += __popc(hh[k] & (kMasked ? tail_mask : 0xFFFFu));
       }
     }
+  };
+  __builtin_amdgcn_s_setprio(0);
+  SFM_STAMP_BEGIN();
+  const int t_partial = (n & 31) ? (n >> 5) : ntiles;  // the tile with padding, if any
+  const int t_full = min(t1, t_partial);
+  for (int t = t0; t < t_full; ++t) {
+    const bool more = t + 1 < t1;  // the last tile of the range loads itself again (in bounds, unused)
+    const uint4* anext = more ? asrc + 64 : asrc;
+    const float4* xnext = more ? xsrc + 16 : xsrc;
+    score_tile(std::false_type{}, anext, xnext);
+    asrc = anext;
+    xsrc = xnext;
   }
+  if (t_partial >= t0 && t_partial < t1) score_tile(std::true_type{}, asrc, xsrc);
+  if constexpr (kFloatCount) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      ce[k] = (int)fe[k];
+      ch[k] = (int)fh[k];
+    }
+  }
+  SFM_STAMP_END(t1 - t0);
   // the two halves of the wave scored different matches for the same 32 hypotheses
   int se[2], sh[2];
 #pragma unroll
@@ -633,6 +746,8 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma_kernel(const
   static_assert(kModel * 8 <= kVec * 32, "the parked models reuse the staging area of the piece vectors");
   __shared__ unsigned char fin[kBlock / 64][64];
   __shared__ uint4 bstage[kBlock / 64][64][kVec][2];
+  SFM_STAMP_ENTRY();
+  __builtin_amdgcn_s_setprio(3);  // the solve runs ahead of the other waves' tile loops (see eh_upper_mfma_kernel)
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long hyp = gid < nb ? gid : nb - 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -726,6 +841,8 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma_kernel(const
   const unsigned tail_mask = tile_tail_mask(n, half);
   const uint4* src = pieces + 4 * (long long)(t0 * 32 + apos) + half;
   const float4* xsrc = reinterpret_cast<const float4*>(xy + t0 * 32 + 16 * half);
+  __builtin_amdgcn_s_setprio(0);
+  SFM_STAMP_BEGIN();
   for (int t = t0; t < t1; ++t, src += 128, xsrc += 16) {
     const bf16x8 A1 = as_bf16x8(src[0]);
     const unsigned vmask = t == (n >> 5) ? tail_mask : 0xFFFFu;
@@ -829,6 +946,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma_kernel(const
       }
     }
   }
+  SFM_STAMP_END(t1 - t0);
   int se[2], sh[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -1446,6 +1564,8 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
                                                                  int grid_tiles, int grid_cams, int grid_splits) {
   __shared__ uint4 bstage[kBlock / 64][64][3][2];
   __shared__ double tstage[kBlock / 64][64][3];
+  SFM_STAMP_ENTRY();
+  __builtin_amdgcn_s_setprio(3);  // the solve runs ahead of the other waves' tile loops (see eh_upper_mfma_kernel)
   // grid_tiles == 0: a 3-D grid (hypothesis tile, camera, split).  Otherwise a 1-D grid of grid_tiles * grid_cams *
   // grid_splits workgroups (grid_splits a multiple of 8) laid out so that linear ids that are equal modulo 8, which the
   // dispatcher deals to the same XCD, work on the same eighth of the splits: every XCD's L2 then only ever holds its own
@@ -1513,6 +1633,8 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
   const f32x16 zero = {0};
   const unsigned tail_mask = tile_tail_mask(m, half);
   const uint4* src = pc + 6 * (t0 * 32 + apos) + half;
+  __builtin_amdgcn_s_setprio(0);
+  SFM_STAMP_BEGIN();
   for (int t = t0; t < t1; ++t, src += 192) {
     const bf16x8 Ax = as_bf16x8(src[0]), Ay = as_bf16x8(src[2]), Aq = as_bf16x8(src[4]);
     const unsigned vmask = t == (m >> 5) ? tail_mask : 0xFFFFu;
@@ -1552,6 +1674,7 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
       }
     }
   }
+  SFM_STAMP_END(t1 - t0);
   const int s0 = cnt[0] + __shfl_xor(cnt[0], 32), s1 = cnt[1] + __shfl_xor(cnt[1], 32);
   const int out = half ? s1 : s0;  // lane L reports hypothesis L = 32*half + col
   if (gid < nb) {
@@ -1899,6 +2022,21 @@ const char* sfm_hip_error_string(int code) {
 
 int sfm_hip_abi_version(void) { return 3; }
 
+#ifdef SFM_CLOCK_STAMPS
+// diagnostic build only: copies the first `slots` stamp records (8 x uint64 each)
+int sfm_debug_clock_stamps(unsigned long long* host_out, int32_t slots, int32_t clear) {
+  if (!host_out || slots <= 0 || slots > kStampSlots) return SFM_EINVAL;
+  SFM_TRY(hipDeviceSynchronize());
+  SFM_TRY(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * (size_t)slots));
+  if (clear) {
+    void* p = nullptr;
+    SFM_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)));
+    SFM_TRY(hipMemset(p, 0, sizeof(unsigned long long) * 8 * (size_t)kStampSlots));
+  }
+  return 0;
+}
+#endif
+
 static int launch_eh_score(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, int32_t* count_e,
                            int32_t* count_h, hipStream_t st) {
   if (!corr || !idx || !count_e || !count_h || n <= 0 || nb < 0) return SFM_EINVAL;
@@ -2013,6 +2151,10 @@ static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n
   const uint4* pieces = (const uint4*)corrm;
   const float2* xy = (const float2*)((const char*)corrm + (size_t)npad * 32);
   const double ke = 2.0 * thr_e * thr_e, kh = thr_h * thr_h;
+  // clamped float counts (see eh_upper_mfma_kernel) for thresholds inside the range their exactness argument covers
+  static const bool float_env = !(getenv("SFM_HIP_EH_FLOATCOUNT") && atoi(getenv("SFM_HIP_EH_FLOATCOUNT")) == 0);
+  const double k1 = uniform_k1(ke);
+  const bool float_count = float_env && k1 > 0x1.0p-45 && k1 < 0.6 && kh > 0x1.0p-45 && kh < 1.0e6;
   // one launch over the hypothesis tiles [t_lo, t_hi) with the match range cut into `sp` pieces
   auto launch = [&](long long t_lo, long long t_hi, int sp) -> int {
     const long long off = t_lo * kBlock;
@@ -2023,15 +2165,17 @@ static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n
       SFM_TRY(hipMemsetAsync(up_h + off, 0, sizeof(int32_t) * cnt, st));
     }
     const dim3 grid((unsigned)(t_hi - t_lo), sp);
-    if (part == 1)  // measurement only: the epipolar half alone (up_h receives zeros)
-      eh_upper_mfma_kernel<true, false><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, ke, kh, xmax, safety,
-                                                                 up_e + off, up_h + off, tps, sp > 1);
-    else if (part == 2)  // measurement only: the transfer half alone
-      eh_upper_mfma_kernel<false, true><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, ke, kh, xmax, safety,
-                                                                 up_e + off, up_h + off, tps, sp > 1);
-    else
-      eh_upper_mfma_kernel<true, true><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, ke, kh, xmax, safety,
-                                                                up_e + off, up_h + off, tps, sp > 1);
+#define SFM_LAUNCH_UPPER(E_, H_, F_)                                                                                                   \
+  eh_upper_mfma_kernel<E_, H_, F_><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, ke, kh, xmax, safety, \
+                                                            up_e + off, up_h + off, tps, sp > 1)
+    if (part == 1) {  // measurement only: the epipolar half alone (up_h receives zeros)
+      if (float_count) SFM_LAUNCH_UPPER(true, false, true); else SFM_LAUNCH_UPPER(true, false, false);
+    } else if (part == 2) {  // measurement only: the transfer half alone
+      if (float_count) SFM_LAUNCH_UPPER(false, true, true); else SFM_LAUNCH_UPPER(false, true, false);
+    } else {
+      if (float_count) SFM_LAUNCH_UPPER(true, true, true); else SFM_LAUNCH_UPPER(true, true, false);
+    }
+#undef SFM_LAUNCH_UPPER
     return check_launch();
   };
   // All workgroups do the same work, so a grid runs in rounds of as many workgroups as the chip holds at once, and a last
@@ -2043,7 +2187,7 @@ static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0LL;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0LL;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, eh_upper_mfma_kernel<true, true>, kBlock, 0) != hipSuccess) return 0LL;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, eh_upper_mfma_kernel<true, true, true>, kBlock, 0) != hipSuccess) return 0LL;
     return (long long)cus * per_cu;
   }();
   static const bool cut_tail = !(getenv("SFM_HIP_EH_TAIL") && atoi(getenv("SFM_HIP_EH_TAIL")) == 0);
@@ -2138,14 +2282,21 @@ constexpr int kMaxDevices = 64;
 void* g_noalloc_ptr[kMaxDevices] = {};
 std::mutex g_noalloc_mutex;
 
-int noalloc_scratch(void** out) {
-  int dev = -1;
-  SFM_TRY(hipGetDevice(&dev));
+// The array of the device that owns `stream` (a NULL stream belongs to the current device).  The first call per device
+// looks the address up with that device current (and restores the caller's device); later calls only read the table.
+int noalloc_scratch(hipStream_t stream, void** out) {
+  int cur = -1, dev = -1;
+  SFM_TRY(hipGetDevice(&cur));
+  dev = cur;
+  if (stream) SFM_TRY(hipStreamGetDevice(stream, &dev));
   if (dev < 0 || dev >= kMaxDevices) return SFM_EINVAL;
   std::lock_guard<std::mutex> lock(g_noalloc_mutex);
   if (!g_noalloc_ptr[dev]) {
     void* p = nullptr;
-    SFM_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (dev != cur) SFM_TRY(hipSetDevice(dev));
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (dev != cur) SFM_TRY(hipSetDevice(cur));
+    if (e != hipSuccess) return (int)e;
     if (!p) return SFM_EINVAL;
     g_noalloc_ptr[dev] = p;
   }
@@ -2160,7 +2311,7 @@ int sfm_eh_score_noalloc(const double* corr, int32_t n, const int32_t* idx, int6
   if (n <= 0 || nb < 0) return SFM_EINVAL;
   if (n > SFM_NOALLOC_MAX_MATCHES) return SFM_ETOOLARGE;
   void* ws = nullptr;
-  SFM_TRY(noalloc_scratch(&ws));
+  SFM_TRY(noalloc_scratch((hipStream_t)stream, &ws));
   // run_eh_score_mixed rewrites every operand of the n (padded to 32) matches and zeroes the 16-byte trailer that the
   // measurement of max |coordinate| accumulates into, so nothing of an earlier call is read
   return run_eh_score_mixed(corr, n, idx, nb, thr_e, thr_h, 0.0, ws, count_e, count_h, (hipStream_t)stream);

@@ -1,13 +1,15 @@
 // SIFT detection and description on the GPU (gfx950 / MI355X only): what the reference obtains from
 // cv2.SIFT_create().detectAndCompute(gray, None) (src/extract_sift.py:104-114, src/utils.py:78-80).
 //
-// The algorithm is Lowe's SIFT with the parameters and the arithmetic order of OpenCV's features2d module
-// (doubled base image, 3 layers per octave, sigma 1.6, contrast threshold 0.04, edge threshold 10, float32
+// The algorithm is Lowe's SIFT with the default parameters of OpenCV's features2d module (base image doubled by
+// cv::resize's INTER_LINEAR rule, 3 layers per octave, sigma 1.6, contrast threshold 0.04, edge threshold 10, float32
 // pyramid, 36-bin orientation histograms, 4 x 4 x 8 descriptors scaled by 512 and saturated to [0, 255]).
 // Everything is float32 with separate multiplies and adds (the library is built with -ffp-contract=off) in one
 // fixed, documented order (ascending taps, window samples in row-major order), so that the detection stage (pyramid,
 // extrema, sub-pixel refinement) is reproducible bit for bit by any IEEE float32 restatement and only expf / powf /
-// cosf / sinf can differ in the last place.
+// cosf / sinf can differ in the last place.  That order is this file's own: OpenCV sums the taps of its symmetric
+// column filter in pairs and computes the first blur's sigma in float32, so its pyramid can differ from this one in the
+// last place; nothing here was compared with OpenCV's output (it is not installed where this was built).
 //
 // Stages and their shapes:
 //   pyramid      separable Gaussian (rows and 64 x 64 column tiles staged in LDS with their reflected margins; the
@@ -23,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/sfm_hip.h"
 
@@ -93,8 +96,14 @@ Plan make_plan(int w, int h) {
   off += (long long)W0 * H0;
   p.tmp_b = off;
   off += (long long)W0 * H0;
-  long long cap = (long long)W0 * H0 / 16;
+  // A pixel of a layer is a 26-neighbour extremum with probability 2 / 27 at most for any continuous noise (7.4 % of the
+  // pixels): a buffer of 1/8 of the base image always holds the candidates of ONE layer, and those of a whole image of any
+  // ordinary content; sfm_sift_detect falls back to one layer at a time when a whole image does not fit.
+  long long cap = (long long)W0 * H0 / 8;
   if (cap < 65536) cap = 65536;
+  // test hook: a smaller buffer, to exercise the layer-by-layer path on small images (read once per process)
+  static const long long cap_env = getenv("SFM_HIP_SIFT_CAND_CAP") ? atoll(getenv("SFM_HIP_SIFT_CAND_CAP")) : 0;
+  if (cap_env > 0) cap = cap_env;
   p.cand_cap = (int)cap;
   p.cand = off;
   off += 4 * cap;
@@ -130,15 +139,21 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   return i >= n ? p - i : i;
 }
 
-// dst(x, y) = bilinear sample of src at (x / 2, y / 2), BORDER_REFLECT; all sums are exact in float32
+// The doubled base image as cv::resize(..., INTER_LINEAR) produces it (the branch SIFT_create() takes by default,
+// enable_precise_upscale = false): pixel centres are aligned, so dst(X) samples src at X / 2 - 0.25 with the border
+// replicated: even X = 2m -> 0.25 src[m-1] + 0.75 src[m], odd X = 2m+1 -> 0.75 src[m] + 0.25 src[m+1], rows first, then
+// columns.  All products and sums are exact in float32 (8-bit pixels times 1/4, 3/4, 1/16 ... 9/16).
 __global__ __launch_bounds__(kBlock) void upsample2x_kernel(const uint8_t* __restrict__ src, int w, int h, float* __restrict__ dst) {
   const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
   if (X >= 2 * w) return;
-  const int x0 = X >> 1, x1 = min(x0 + (X & 1), w - 1);
-  const int y0 = Y >> 1, y1 = min(y0 + (Y & 1), h - 1);
-  const float a = (float)src[(long long)y0 * w + x0] * 0.5f + (float)src[(long long)y0 * w + x1] * 0.5f;
-  const float b = (float)src[(long long)y1 * w + x0] * 0.5f + (float)src[(long long)y1 * w + x1] * 0.5f;
-  dst[(long long)Y * 2 * w + X] = a * 0.5f + b * 0.5f;
+  const int mx = X >> 1, my = Y >> 1;
+  const int x0 = (X & 1) ? mx : max(mx - 1, 0), x1 = (X & 1) ? min(mx + 1, w - 1) : mx;
+  const int y0 = (Y & 1) ? my : max(my - 1, 0), y1 = (Y & 1) ? min(my + 1, h - 1) : my;
+  const float ax = (X & 1) ? 0.75f : 0.25f, bx = 1.0f - ax;  // weights of x0 and x1
+  const float ay = (Y & 1) ? 0.75f : 0.25f, by = 1.0f - ay;
+  const float a = (float)src[(long long)y0 * w + x0] * ax + (float)src[(long long)y0 * w + x1] * bx;
+  const float b = (float)src[(long long)y1 * w + x0] * ax + (float)src[(long long)y1 * w + x1] * bx;
+  dst[(long long)Y * 2 * w + X] = a * ay + b * by;
 }
 
 // one workgroup = 256 consecutive pixels of one row, staged in LDS with the reflected margins
@@ -228,11 +243,11 @@ __global__ __launch_bounds__(kBlock) void downsample2_kernel(const float* __rest
 }
 
 // grid = (x tiles, interior rows, layers 1..kLayers); candidate = (octave, layer, r, c)
-__global__ __launch_bounds__(kBlock) void extrema_kernel(const float* __restrict__ dog, int w, int h, int octave, float thr,
+__global__ __launch_bounds__(kBlock) void extrema_kernel(const float* __restrict__ dog, int w, int h, int octave, int first_layer, float thr,
                                                          int4* __restrict__ cand, int cand_cap, int* __restrict__ counters) {
   const int c = kBorder + blockIdx.x * blockDim.x + threadIdx.x;
   const int r = kBorder + blockIdx.y;
-  const int layer = 1 + blockIdx.z;
+  const int layer = first_layer + blockIdx.z;
   if (c >= w - kBorder) return;
   const long long plane = (long long)w * h;
   const float* cur = dog + layer * plane;
@@ -637,6 +652,7 @@ int sfm_sift_detect(const uint8_t* gray, int32_t w, int32_t h, void* workspace, 
     const double prev = pow(kf, (double)(i - 1)) * kSigmaD, total = prev * kf;
     sig[i] = sqrt(total * total - prev * prev);
   }
+  const float thr = (float)floor(0.5 * kContrastThr / kLayers * 255.0);
   for (int o = 0; o < p.noct; ++o) {
     const int W = p.W[o], H = p.H[o];
     const long long plane = (long long)W * H;
@@ -652,21 +668,41 @@ int sfm_sift_detect(const uint8_t* gray, int32_t w, int32_t h, void* workspace, 
       if (rc) return rc;
     }
     if (W > 2 * kBorder && H > 2 * kBorder) {
-      const float thr = (float)floor(0.5 * kContrastThr / kLayers * 255.0);
-      extrema_kernel<<<dim3(div_up(W - 2 * kBorder, kBlock), H - 2 * kBorder, kLayers), kBlock, 0, st>>>(dg, W, H, o, thr, cand, p.cand_cap, counters);
+      extrema_kernel<<<dim3(div_up(W - 2 * kBorder, kBlock), H - 2 * kBorder, kLayers), kBlock, 0, st>>>(dg, W, H, o, 1, thr, cand, p.cand_cap, counters);
       SIFT_TRY((hipError_t)check_launch());
     }
   }
   int host_counts[4] = {0, 0, 0, 0};
   SIFT_TRY(hipMemcpyAsync(host_counts, counters, 16, hipMemcpyDeviceToHost, st));
   SIFT_TRY(hipStreamSynchronize(st));
-  if (host_counts[0] > p.cand_cap) return SFM_ETOOLARGE;
-  if (host_counts[0] > 0) {
-    refine_orient_kernel<<<div_up(host_counts[0], 64), 64, 0, st>>>(ws, to_dev(p), cand, p.cand_cap, counters, keypoints, capacity);
-    SIFT_TRY((hipError_t)check_launch());
-    SIFT_TRY(hipMemcpyAsync(host_counts, counters, 16, hipMemcpyDeviceToHost, st));
-    SIFT_TRY(hipStreamSynchronize(st));
+  if (host_counts[0] <= p.cand_cap) {
+    if (host_counts[0] > 0) {
+      refine_orient_kernel<<<div_up(host_counts[0], 64), 64, 0, st>>>(ws, to_dev(p), cand, p.cand_cap, counters, keypoints, capacity);
+      SIFT_TRY((hipError_t)check_launch());
+    }
+  } else {
+    // more extrema than the candidate buffer holds (a noise image): the pyramid is complete, so the extrema are found again
+    // and refined one layer at a time; the keypoint counter keeps running across the layers
+    for (int o = 0; o < p.noct; ++o) {
+      const int W = p.W[o], H = p.H[o];
+      if (!(W > 2 * kBorder && H > 2 * kBorder)) continue;
+      for (int layer = 1; layer <= kLayers; ++layer) {
+        SIFT_TRY(hipMemsetAsync(counters, 0, 4, st));
+        extrema_kernel<<<dim3(div_up(W - 2 * kBorder, kBlock), H - 2 * kBorder, 1), kBlock, 0, st>>>(ws + p.dog[o], W, H, o, layer, thr, cand, p.cand_cap,
+                                                                                                   counters);
+        SIFT_TRY((hipError_t)check_launch());
+        SIFT_TRY(hipMemcpyAsync(host_counts, counters, 16, hipMemcpyDeviceToHost, st));
+        SIFT_TRY(hipStreamSynchronize(st));
+        if (host_counts[0] > p.cand_cap) return SFM_ETOOLARGE;  // cannot happen for a buffer of 1/8 of the base image (see make_plan)
+        if (host_counts[0] > 0) {
+          refine_orient_kernel<<<div_up(host_counts[0], 64), 64, 0, st>>>(ws, to_dev(p), cand, p.cand_cap, counters, keypoints, capacity);
+          SIFT_TRY((hipError_t)check_launch());
+        }
+      }
+    }
   }
+  SIFT_TRY(hipMemcpyAsync(host_counts, counters, 16, hipMemcpyDeviceToHost, st));
+  SIFT_TRY(hipStreamSynchronize(st));
   *count = host_counts[1];
   return host_counts[1] > capacity ? SFM_ETOOLARGE : 0;
 }

@@ -249,6 +249,28 @@ def gen_eh_ransac():
     save("eh_ransac.npz", **out)
 
 
+def gen_eh_ransac_many():
+    """Thirty seeded run_ransac runs of the reference at 300, 500 and 1500 matches (ten seeds each, scenes of varying inlier
+    and planar share) with their full count traces: the sample stream follows from the seed, so a consumer can tell which
+    iterations drew a repeated index (a rank-deficient system whose null vector LAPACK picks arbitrarily) and which of
+    them were record events."""
+    out = {}
+    runs = []
+    for n in (300, 500, 1500):
+        for j in range(10):
+            sseed, rseed = 1000 + 37 * j + n, 500 + 11 * j + n
+            inl, pl = 0.55 + 0.04 * (j % 5), 0.45 + 0.05 * (j % 4)
+            sc = synthetic.two_view_scene(n=n, inlier_ratio=inl, planar_ratio=pl, seed=sseed)
+            R, T, m, cE, cH, nd = traced_run_ransac(sc, rseed)
+            tag = f"r{len(runs):02d}"
+            print("eh_ransac_many", tag, "n", n, "iterations", len(cH), "inliers", int(m.sum()), flush=True)
+            runs.append([n, inl, pl, sseed, rseed, len(cH)])
+            out.update({f"{tag}_R": R, f"{tag}_T": T, f"{tag}_inliers": np.packbits(m), f"{tag}_cE": cE.astype(np.uint16),
+                        f"{tag}_cH": cH.astype(np.uint16), f"{tag}_next_draws": nd})
+    out["runs"] = np.array(runs, np.float64)  # n, inlier share, planar share, scene seed, run seed, iterations
+    save("eh_ransac_many.npz", **out)
+
+
 def gen_reconstruction():
     sc = synthetic.two_view_scene(n=500, inlier_ratio=0.75, planar_ratio=0.6, seed=51)
     rel = [synthetic.rot_y(0.05), synthetic.rot_x(0.02) @ synthetic.rot_y(0.04), synthetic.rot_y(-0.03)]
@@ -261,6 +283,9 @@ def gen_reconstruction():
 
 
 if __name__ == "__main__":
+    if "--only-many" in sys.argv:
+        gen_eh_ransac_many()
+        sys.exit(0)
     pack = gen_solvers_and_scoring()
     gen_decomp(*pack)
     gen_triangulate(pack[0], pack[1], pack[2])
@@ -268,4 +293,5 @@ if __name__ == "__main__":
     gen_lm()
     gen_reconstruction()
     gen_eh_ransac()
+    gen_eh_ransac_many()
     gen_t_ransac()

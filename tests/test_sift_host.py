@@ -34,17 +34,20 @@ def test_descriptor_is_normalised_clipped_and_rotation_covariant():
     img = (255 * (img - img.min()) / (img.max() - img.min())).astype(np.uint8)
     kp, desc, full = osift.detect_and_compute(img)
     kp90, desc90, full90 = osift.detect_and_compute(np.ascontiguousarray(np.rot90(img)))  # exact 90 degree rotation
-    assert len(full) > 10 and abs(len(full) - len(full90)) <= 2
+    # the default (not 'precise') upscale is not symmetric about the image centre, so a few border keypoints come and go
+    assert len(full) > 10 and abs(len(full) - len(full90)) <= 0.25 * len(full)
     assert desc.dtype == np.uint8 and desc.max() <= 255
     norms = np.linalg.norm(desc.astype(float), axis=1)
     assert np.all(norms > 400) and np.all(norms < 560)  # 512 up to clipping and rounding
-    # rot90 maps (x, y) -> (y, w - 1 - x); descriptors of corresponding keypoints stay close
+    # rot90 maps (x, y) -> (y, w - 1 - x); descriptors of corresponding keypoints stay close.  Reported positions carry the
+    # quarter-pixel bias of the default upscale (dst X samples src at X / 2 - 0.25: reported = true + 0.25 on both axes),
+    # which the rotation turns into + 0.5 on the flipped axis.
     hits = 0
     for i, k in enumerate(full):
-        target = np.array([k[1], w - 1 - k[0]])
+        target = np.array([k[1], w - 1 - k[0] + 0.5])
         d = np.linalg.norm(kp90 - target, axis=1)
         j = int(np.argmin(d))
-        if d[j] < 0.75 and abs(full90[j][2] - k[2]) < 0.1 * k[2]:
+        if d[j] < 0.3 and abs(full90[j][2] - k[2]) < 0.1 * k[2]:
             dist = np.linalg.norm(desc[i].astype(float) - desc90[j].astype(float))
             if dist < 120:
                 hits += 1

@@ -63,6 +63,13 @@ def test_noalloc_entry_point_matches_workspace_entry_point_twice():
     ok = np.array([len(set(r[:8])) == 8 and len(set(r[8:])) == 4 for r in idx2_h])
     np.testing.assert_array_equal(ce2[ok], oE[ok])
     np.testing.assert_array_equal(ch2[ok], oH[ok])
+    # on a stream of the caller's own (the scratch array is looked up for the device that owns the stream)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ce3, ch3, re3, rh3 = _both(torch, C, ops, lib, corr2, idx2, thr)
+    np.testing.assert_array_equal(ce3, re2)
+    np.testing.assert_array_equal(ch3, rh2)
 
 
 def test_noalloc_entry_point_rejects_oversize_and_bad_arguments():
