@@ -135,6 +135,11 @@ int sfm_eh_score_noalloc(const double* corr, int32_t n, const int32_t* idx, int6
 int sfm_eh_models_f64(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double* F_out, double* E_out,
                       double* H_out, void* stream);
 
+/* estimate_F_DLT (src/ransac_algorithm.py:216-263, homography = 0, n >= 8) or estimate_H_DLT (:266-293, homography = 1,
+ * n >= 4) over ALL n given correspondences: out = double[9], row-major F (sign arbitrary, as the singular vector's) or
+ * H divided by H[2][2].  One wave; for callers of those two functions with more than a minimal sample. */
+int sfm_dlt_general_f64(const double* corr, int32_t n, int32_t homography, double* out, void* stream);
+
 /* Inlier mask (uint8[n], 0/1) and count (int32[1], may be NULL) of one essential matrix:
  * the symmetric epipolar test of src/ransac_algorithm.py:98-102 / :133-138. */
 int sfm_epipolar_mask_f64(const double* E, const double* corr, int32_t n, double thr, uint8_t* mask, int32_t* count,

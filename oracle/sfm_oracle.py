@@ -308,7 +308,8 @@ def estimate_E_robust(K, x1, x2, pixel_threshold, trace=None, max_iterations=Non
     """src/ransac_algorithm.py:57-173, consuming the global legacy np.random stream
     in the reference's order (8 then 4 integers per iteration).
 
-    trace: optional dict that receives lists 'cE', 'cH', 'idx' and 'iterations'.
+    trace: optional dict that receives lists 'cE', 'cH', 'idx', 'events' ((iteration, 'E'|'H', accepted) per record event)
+    and 'iterations'.
     max_iterations: safety stop for tests (the reference has none).
     """
     N = x1.shape[1]
@@ -329,6 +330,8 @@ def estimate_E_robust(K, x1, x2, pixel_threshold, trace=None, max_iterations=Non
         mask = epipolar_mask(E, x1, x2, thr)
         nE = int(np.sum(mask))
         if nE > best_E:
+            if trace is not None:
+                trace.setdefault("events", []).append((it, "E", True))
             best_E = nE
             R_best, T_best, _ = essential_to_RT(E, x1, x2)
             eps_E = best_E / N
@@ -355,6 +358,8 @@ def estimate_E_robust(K, x1, x2, pixel_threshold, trace=None, max_iterations=Non
                 pick = (Rba, Tba, na, ma) if na > nE else None
             else:
                 pick = (Rbb, Tbb, nb, mb) if nb > nE else None
+            if trace is not None:
+                trace.setdefault("events", []).append((it, "H", pick is not None))
             if pick is not None:
                 R_best, T_best, best_E, inliers = pick
                 eps_H = best_H / N

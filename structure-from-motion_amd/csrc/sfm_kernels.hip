@@ -997,6 +997,108 @@ __global__ __launch_bounds__(kBlock) void eh_models_kernel(const double4* __rest
 }
 
 // ---------------------------------------------------------------------------------------
+// DLT over ANY number of correspondences (src/ransac_algorithm.py:216-263 and :266-293 loop over all columns they are
+// given; the pipeline itself only ever passes minimal samples, which the in-register solvers above serve).
+// One wave: every lane folds its share of the rows of the n x 9 (F) or 2n x 9 (H) system into a 9 x 9 upper triangle
+// with Givens rotations (a QR factorisation row by row: the right singular vectors of the triangle are those of the whole
+// system, and nothing is squared), the 64 triangles are merged by a butterfly of the same rotations, and the right
+// singular vector of the smallest singular value of the merged triangle comes from the one-sided Jacobi of sfm_math.hpp.
+// ---------------------------------------------------------------------------------------
+template <int kFrom>
+__device__ __forceinline__ void givens_fold_row(double (&R)[9][9], double (&a)[9]) {
+#pragma unroll
+  for (int k = kFrom; k < 9; ++k) {
+    const double r = sqrt(fma(R[k][k], R[k][k], a[k] * a[k]));
+    const bool act = r > 0.0;
+    const double c = act ? R[k][k] / r : 1.0, sn = act ? a[k] / r : 0.0;
+#pragma unroll
+    for (int j = k; j < 9; ++j) {
+      const double t = fma(c, R[k][j], sn * a[j]);
+      a[j] = fma(-sn, R[k][j], c * a[j]);
+      R[k][j] = t;
+    }
+  }
+}
+
+template <int kRow>
+__device__ __forceinline__ void merge_triangle_rows(double (&R)[9][9], const double (&O)[9][9]) {
+  if constexpr (kRow < 9) {
+    double a[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) a[j] = j >= kRow ? O[kRow][j] : 0.0;
+    givens_fold_row<kRow>(R, a);
+    merge_triangle_rows<kRow + 1>(R, O);
+  }
+}
+
+__global__ __launch_bounds__(64) void dlt_general_kernel(const double4* __restrict__ corr, int n, int homography, double* __restrict__ out) {
+  const int lane = threadIdx.x;
+  double R[9][9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) R[i][j] = 0.0;
+  for (int p = lane; p < n; p += 64) {
+    const double4 c = corr[p];
+    const double x1 = c.x, y1 = c.y, x2 = c.z, y2 = c.w;
+    if (homography) {  // :281-282
+      double a[9] = {-x1, -y1, -1.0, 0.0, 0.0, 0.0, x2 * x1, x2 * y1, x2};
+      givens_fold_row<0>(R, a);
+      double b[9] = {0.0, 0.0, 0.0, -x1, -y1, -1.0, y2 * x1, y2 * y1, y2};
+      givens_fold_row<0>(R, b);
+    } else {  // :243-253
+      double a[9] = {x1 * x2, x1 * y2, x1, y1 * x2, y1 * y2, y1, x2, y2, 1.0};
+      givens_fold_row<0>(R, a);
+    }
+  }
+#pragma unroll 1
+  for (int off = 32; off > 0; off >>= 1) {
+    double O[9][9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) O[i][j] = j >= i ? __shfl_xor(R[i][j], off) : 0.0;
+    merge_triangle_rows<0>(R, O);
+  }
+  // every lane now holds a triangle of the whole system (equal up to rounding and row signs); lane 0's is used
+  double g[9][9], v[9][9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) g[i][j] = __shfl(R[i][j], 0);
+  jacobi_svd<double, 9>(g, v);
+  double best = INFINITY;
+  int kmin = 0;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    double nj = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nj = fma(g[i][j], g[i][j], nj);
+    if (nj < best) {
+      best = nj;
+      kmin = j;
+    }
+  }
+  if (lane == 0) {
+    double q[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) t = (j == kmin) ? v[i][j] : t;  // static indices: the column is selected, not addressed
+      q[i] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      if (homography)
+        out[i] = q[i] / q[8];  // reshape(3, 3) / H[2, 2]  (:290-293)
+      else
+        out[3 * (i % 3) + i / 3] = q[i];  // F = v.reshape(3, 3).T  (:261)
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Record-event kernels: one point per lane.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int block_count(bool flag) {
@@ -1371,6 +1473,16 @@ __device__ __forceinline__ void load_t_sample(const double* __restrict__ pts, in
   }
 }
 
+// Two DIFFERENT indices can name the same correspondence twice (a keypoint with two orientations matched to one 3-D
+// point): the 6 x 3 system then has rank 2 exactly as for a repeated index, and gelsd's minimum-norm solution is what
+// the reference computes (src/estimate_translation.py:104), so such a sample takes solve_T2's closed form as well.
+__device__ __forceinline__ bool same_correspondence(const double (&x)[2][3], const double (&r)[2][3]) {
+  bool same = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) same = same && x[0][i] == x[1][i] && r[0][i] == r[1][i];
+  return same;
+}
+
 // grid = (hypothesis tiles, cameras, point splits)
 __global__ __launch_bounds__(kBlock) void t_score_kernel(const double* __restrict__ pts_all, CamOffsets offs, const int32_t* __restrict__ idx,
                                                          long long nb, double thr2, int* __restrict__ counts, int points_per_split,
@@ -1385,7 +1497,7 @@ __global__ __launch_bounds__(kBlock) void t_score_kernel(const double* __restric
   {
     double x[2][3], r[2][3];
     load_t_sample(pts, m, pair, x, r);
-    solve_T2<double>(x, r, pair[0] == pair[1], T);
+    solve_T2<double>(x, r, pair[0] == pair[1] || same_correspondence(x, r), T);
   }
   const int j0 = blockIdx.z * points_per_split;
   const int j1 = min(m, j0 + points_per_split);
@@ -1410,7 +1522,7 @@ __global__ __launch_bounds__(kBlock) void t_models_kernel(const double* __restri
   if (gid >= nb) return;
   double x[2][3], r[2][3], T[3];
   load_t_sample(pts, m, idx + 2 * gid, x, r);
-  solve_T2<double>(x, r, idx[2 * gid] == idx[2 * gid + 1], T);
+  solve_T2<double>(x, r, idx[2 * gid] == idx[2 * gid + 1] || same_correspondence(x, r), T);
 #pragma unroll
   for (int i = 0; i < 3; ++i) T_out[3 * gid + i] = T[i];
 }
@@ -1438,7 +1550,7 @@ __global__ __launch_bounds__(kBlock) void t_upper_kernel(const double* __restric
   {
     double T[3], x[2][3], r[2][3];
     load_t_sample(pts, m, pair, x, r);
-    solve_T2<double>(x, r, pair[0] == pair[1], T);
+    solve_T2<double>(x, r, pair[0] == pair[1] || same_correspondence(x, r), T);
 #pragma unroll
     for (int i = 0; i < 3; ++i) Tf[i] = (float)T[i];
     const double P = bounds.rmax[cam] + fmax(fabs(T[0]), fmax(fabs(T[1]), fabs(T[2])));
@@ -1595,7 +1707,7 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
     {
       double x[2][3], r[2][3];
       load_t_sample(pts, m, pair, x, r);
-      solve_T2<double>(x, r, pair[0] == pair[1], T);
+      solve_T2<double>(x, r, pair[0] == pair[1] || same_correspondence(x, r), T);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) tstage[wave][lane][i] = T[i];
@@ -1839,7 +1951,7 @@ __global__ void t_winner_kernel(const double* __restrict__ pts_all, CamOffsets o
   const int32_t* pair = idx + 2 * ((long long)cam * nb + h);
   double x[2][3], r[2][3], T[3];
   load_t_sample(pts, m, pair, x, r);
-  solve_T2<double>(x, r, pair[0] == pair[1], T);
+  solve_T2<double>(x, r, pair[0] == pair[1] || same_correspondence(x, r), T);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) T_best[3 * cam + k] = T[k];
@@ -2556,6 +2668,13 @@ int sfm_eh_models_f64(const double* corr, int32_t n, const int32_t* idx, int64_t
   if (!corr || !idx || n <= 0 || nb < 0) return SFM_EINVAL;
   if (nb == 0) return 0;
   eh_models_kernel<<<div_up(nb, kBlock), kBlock, 0, (hipStream_t)stream>>>((const double4*)corr, n, idx, nb, F_out, E_out, H_out);
+  return check_launch();
+}
+
+int sfm_dlt_general_f64(const double* corr, int32_t n, int32_t homography, double* out, void* stream) {
+  clear_stale_error();
+  if (!corr || !out || n < (homography ? 4 : 8)) return SFM_EINVAL;
+  dlt_general_kernel<<<1, 64, 0, (hipStream_t)stream>>>((const double4*)corr, n, homography ? 1 : 0, out);
   return check_launch();
 }
 

@@ -35,6 +35,7 @@ _SIGS = {
     "sfm_eh_best_collect": (_c.c_int, [_P, _P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_int32,
                                        _P, _c.c_int64, _P, _P, _P]),
     "sfm_eh_models_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _P, _P, _P, _P]),
+    "sfm_dlt_general_f64": (_c.c_int, [_P, _c.c_int32, _c.c_int32, _P, _P]),
     "sfm_epipolar_mask_f64": (_c.c_int, [_P, _P, _c.c_int32, _c.c_double, _P, _P, _P]),
     "sfm_transfer_mask_f64": (_c.c_int, [_P, _P, _c.c_int32, _c.c_double, _P, _P, _P]),
     "sfm_epipolar_errors_f64": (_c.c_int, [_P, _P, _P, _c.c_int32, _c.c_int64, _P, _P]),

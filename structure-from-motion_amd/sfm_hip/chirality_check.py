@@ -9,15 +9,20 @@ from . import ops
 
 def perform_chirality_check(P2s, x1, x2):
     """Reference: src/chirality_check.py:5-36.  Triangulates every correspondence under each
-    of the four candidate second cameras (first camera [I|0]) and returns the candidate with
-    the most points in front of both cameras (first strict maximum) and that count."""
-    if len(P2s) != 4:
-        raise NotImplementedError("the GPU kernel scores exactly four candidates, as the reference pipeline does")
-    Pd = C.dev(np.stack([np.asarray(p, np.float64).reshape(12) for p in P2s]))
+    of the candidate second cameras (first camera [I|0]; four in the pipeline, any number here) and returns the
+    candidate with the most points in front of both cameras (first strict maximum) and that count."""
+    if len(P2s) == 0:
+        raise ValueError("no candidate cameras")
+    P = [np.asarray(p, np.float64).reshape(12) for p in P2s]
     if np.asarray(x1).shape[1] == 0:
-        counts = np.zeros(4, np.int32)
+        counts = np.zeros(len(P), np.int32)
     else:
-        counts = ops.chirality4(Pd, C.dev(ops.pack_corr(x1, x2)), None).cpu().numpy()
+        corr = C.dev(ops.pack_corr(x1, x2))
+        counts = []
+        for g in range(0, len(P), 4):  # the kernel scores four candidates per launch (what the pipeline passes); pad the last group
+            group = P[g : g + 4] + [P[-1]] * (4 - len(P[g : g + 4]))
+            counts.extend(ops.chirality4(C.dev(np.stack(group)), corr, None).cpu().numpy()[: len(P[g : g + 4])])
+        counts = np.asarray(counts, np.int32)
     best_idx, n = select_best_from_counts(counts)
     return P2s[best_idx], n
 

@@ -256,6 +256,15 @@ def eh_models(corr, idx, want_F=False):
     return (F, E, H) if want_F else (E, H)
 
 
+def dlt_general(corr, homography):
+    """estimate_F_DLT / estimate_H_DLT over all rows of corr (float64 [n][4], n >= 8 / 4): float64 [9], row-major."""
+    torch = C.torch_cuda()
+    lib = C.load_library()
+    out = _empty((9,), torch.float64)
+    C.check(lib.sfm_dlt_general_f64(C.dptr(corr), corr.shape[0], 1 if homography else 0, C.dptr(out), C.stream_ptr()))
+    return out
+
+
 def epipolar_mask(E, corr, thr):
     """E: float64 [9] device -> (mask uint8 [N], count int32 [1])."""
     torch = C.torch_cuda()

@@ -55,6 +55,7 @@ class ReplayState:
         self.inliers = None
         self.pending_E = None  # index row of the latest E record event whose R, T, inliers have not been computed yet
         self.events = []  # (iteration, 'E'|'H', accepted) for logging and tests
+        self.event_rows = []  # the index row of each of them
 
     def limit(self):
         return max(self.E_iters, self.H_iters)
@@ -110,6 +111,7 @@ def replay_block(st, idx, cE, cH, backend, exact=None):
             st.pending_E = np.array(idx[j])
             st.E_iters = ransac_iters(st.best_E / st.n, S_E)
             st.events.append((st.it, "E", True))
+            st.event_rows.append(np.array(idx[j]))
         nH = int(cH[j])
         if nH > st.best_H:  # :124-169
             st.best_H = nH
@@ -129,6 +131,7 @@ def replay_block(st, idx, cE, cH, backend, exact=None):
                 st.H_iters = ransac_iters(st.best_H / st.n, S_H)
                 st.E_iters = ransac_iters(st.best_E / st.n, S_E)
             st.events.append((st.it, "H", pick is not None))
+            st.event_rows.append(np.array(idx[j]))
         st.it += 1
         j += 1
     return j
@@ -330,18 +333,20 @@ def estimate_R(K, x_pairs, pixel_threshold):
 # ---- single-model functions of the reference module, each one GPU call --------------------
 
 
-def _sample_corr(x1s, x2s, need):
+def _sample_corr(x1s, x2s, least):
     x1s = np.asarray(x1s, np.float64)
     x2s = np.asarray(x2s, np.float64)
-    if x1s.shape[1] != need:
-        raise NotImplementedError(f"the in-register solver takes exactly {need} correspondences, got {x1s.shape[1]}")
+    if x1s.shape[1] < least:
+        raise ValueError(f"at least {least} correspondences are needed, got {x1s.shape[1]}")
     return ops.pack_corr(x1s, x2s)
 
 
 def estimate_F_DLT(x1s, x2s):
-    """Reference: src/ransac_algorithm.py:216-263 for the minimal 8-point case (sign of F is
-    arbitrary there as well: it is a singular vector)."""
+    """Reference: src/ransac_algorithm.py:216-263 (the sign of F is arbitrary there as well: it is a singular vector).
+    Eight correspondences go through the in-register solver of the scoring kernels, more through sfm_dlt_general_f64."""
     corr = _sample_corr(x1s, x2s, 8)
+    if corr.shape[0] > 8:
+        return ops.dlt_general(C.dev(corr), False).cpu().numpy().reshape(3, 3)
     idx = np.concatenate([np.arange(8), np.arange(4)])[None, :]
     F, _, _ = ops.eh_models(C.dev(corr), C.dev(idx, np.int32), want_F=True)
     return F.cpu().numpy().reshape(3, 3)
@@ -353,8 +358,10 @@ def enforce_essential(E):
 
 
 def estimate_H_DLT(x1s, x2s):
-    """Reference: src/ransac_algorithm.py:266-293 (four correspondences)."""
+    """Reference: src/ransac_algorithm.py:266-293 (four correspondences: the in-register solver; more: sfm_dlt_general_f64)."""
     corr = _sample_corr(x1s, x2s, 4)
+    if corr.shape[0] > 4:
+        return ops.dlt_general(C.dev(corr), True).cpu().numpy().reshape(3, 3)
     corr8 = np.concatenate([corr, corr], axis=0)
     idx = np.concatenate([np.arange(8), np.arange(4)])[None, :]
     _, H = ops.eh_models(C.dev(corr8), C.dev(idx, np.int32))

@@ -221,6 +221,56 @@ def test_single_model_functions(sfm, golden):
     assert et.count_inliers(rs["x_norm"], rs["X"], rs["R"], t["T"][j], float(t["thr"])) == t["counts"][j]
 
 
+def test_dlt_over_any_number_of_correspondences(sfm, golden):
+    """estimate_F_DLT and estimate_H_DLT of the reference loop over every column they are given (src/ransac_algorithm.py
+    :240-253, :280-282): more than a minimal sample goes through sfm_dlt_general_f64.  The null vector of a well
+    conditioned system agrees with LAPACK's to a few ulp of the condition number; its sign is arbitrary for F."""
+    from sfm_hip import chirality_check as cc
+    from sfm_hip import ransac_algorithm as ra
+
+    g = golden("eh_scoring.npz")
+    d = golden("decomp.npz")
+    sc = two_view(g["scene"])
+    x1 = orc.normalize_K(sc["K"], sc["x1"])
+    x2 = orc.normalize_K(sc["K"], sc["x2"])
+    inl = np.flatnonzero(sc["is_inlier"])
+    rng = np.random.RandomState(5)
+    for n in (9, 13, 64, 65, 200, len(inl)):
+        cols = inl[rng.permutation(len(inl))[:n]]
+        F = ra.estimate_F_DLT(x1[:, cols], x2[:, cols])
+        Fo = orc.estimate_F_DLT(x1[:, cols], x2[:, cols])
+        assert abs(np.linalg.norm(F) - 1.0) < 1e-12
+        np.testing.assert_allclose(np.sign(np.sum(F * Fo)) * F, Fo, atol=1e-9), n
+        # the residual of the system itself: as small as LAPACK's
+        A = orc.dlt_rows_F(x1[:, cols], x2[:, cols])
+        assert np.linalg.norm(A @ F.T.reshape(9)) <= np.linalg.norm(A @ Fo.T.reshape(9)) * (1 + 1e-6) + 1e-13
+    # a plane: the homography of the scene's planar points from 5 ... all of them
+    planar = np.flatnonzero(sc["on_plane"]) if "on_plane" in sc else None
+    if planar is None or len(planar) < 12:
+        Hs = np.array([[1.02, 0.03, 0.01], [-0.02, 0.97, 0.04], [0.05, -0.03, 1.0]])
+        p1 = np.vstack([rng.uniform(-0.5, 0.5, (2, 300)), np.ones((1, 300))])
+        p2 = Hs @ p1
+        p2 = p2 / p2[2] + np.vstack([rng.normal(0, 1e-3, (2, 300)), np.zeros((1, 300))])
+    else:
+        p1, p2 = x1[:, planar], x2[:, planar]
+    for n in (5, 6, 33, 100, p1.shape[1]):
+        H = ra.estimate_H_DLT(p1[:, :n], p2[:, :n])
+        Ho = orc.estimate_H_DLT(p1[:, :n], p2[:, :n])
+        np.testing.assert_allclose(H, Ho, rtol=1e-7, atol=1e-9), n
+    with pytest.raises(ValueError):
+        ra.estimate_F_DLT(x1[:, :7], x2[:, :7])
+    with pytest.raises(ValueError):
+        ra.estimate_H_DLT(x1[:, :3], x2[:, :3])
+    # any number of candidate cameras: groups of four on the same kernel
+    P2s = list(d["P2s"])
+    xi1, xi2 = x1[:, sc["is_inlier"]], x2[:, sc["is_inlier"]]
+    for cands in (P2s[:1], P2s[:2], P2s[1:4], P2s + P2s[:3], P2s[2:] + P2s):
+        bestP, cnt = cc.perform_chirality_check(cands, xi1, xi2)
+        ob, oc = orc.perform_chirality_check(cands, xi1, xi2)
+        assert cnt == oc
+        np.testing.assert_array_equal(bestP, ob)
+
+
 def test_triangulate_api_and_edge_cases(sfm, golden):
     t = golden("triangulate.npz")
     g = golden("eh_scoring.npz")

@@ -5,10 +5,10 @@ Samples are drawn with replacement (src/ransac_algorithm.py:94,116), so a few pe
 system is rank deficient and its null vector is whatever LAPACK (there) or the in-register solver (here) happens to return,
 so its counts and models are not comparable.  The test therefore
   * compares the counts of EVERY iteration of every run that drew no repeated index with the reference's trace (exactly),
-  * calls a run 'flagged' when a repeated-index iteration differs in a count or is a record event on the GPU side,
-  * asserts that every unflagged run reproduces the reference's rotation, translation, inlier mask, iteration count and
-    position of the global sample stream, and reports how many of all thirty do (seeded_runs_report, also used by
-    profiles/tools/seeded_runs_report.py)."""
+  * counts the repeated-index iterations, the count differences on them and the record events that fall on one,
+  * asserts that every run without such a record event reproduces the reference's rotation, translation, inlier mask,
+    iteration count and position of the global sample stream -- and, as measured on this fixture, that all thirty do
+    (seeded_runs_report, also used by profiles/tools/seeded_runs_report.py)."""
 import os
 
 import numpy as np
@@ -62,11 +62,13 @@ def test_thirty_seeded_runs_against_the_reference():
     rows = seeded_runs_report()
     assert len(rows) == 30
     checked = sum(r["iterations"] for r in rows)
-    assert checked > 50000
+    assert checked > 100000
     assert sum(r["count_mismatches_without_repeated_index"] for r in rows) == 0  # every comparable iteration of every run
-    unflagged = [r for r in rows if not r["flagged"]]
-    assert len(unflagged) >= 10
-    assert all(r["identical_to_reference"] for r in unflagged), [r for r in unflagged if not r["identical_to_reference"]]
     same = sum(r["identical_to_reference"] for r in rows)
-    print(f"seeded runs identical to the reference: {same} of 30 ({len(unflagged)} unflagged, all identical); iterations compared: {checked}")
-    assert same >= 20
+    on_rep = sum(r["record_events_on_repeated_index"] > 0 for r in rows)
+    print(f"seeded runs identical to the reference: {same} of 30; iterations compared: {checked}, "
+          f"{sum(r['iterations_with_repeated_index'] for r in rows)} of them with a repeated index "
+          f"({sum(r['count_differences_on_repeated_index'] for r in rows)} count differences there), runs with a record event on one: {on_rep}")
+    # a run without a record event on a repeated-index sample must reproduce the reference; on this fixture all thirty do
+    assert all(r["identical_to_reference"] for r in rows if r["record_events_on_repeated_index"] == 0)
+    assert same == 30
