@@ -64,6 +64,26 @@ def load_profile_counters(matches, hyps):
         return json.load(f), os.path.relpath(files[-1], ROOT)
 
 
+def load_traffic(matches, hyps):
+    """Memory-side bytes per call of the exact E/H scorer on the default workload from the newest profiles/r*_traffic.json
+    (profiles/tools/traffic_probe.py: the same library call on the same shape, one launch at a time under separate
+    rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes): the sum over the launches one call makes."""
+    import glob
+
+    if (matches, hyps) != (10000, 1000000):
+        return None, None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None, None
+    with open(files[-1]) as f:
+        t = json.load(f)
+    grid = (hyps + 255) // 256 * 256
+    parts = {k: v for k, v in t.items() if k.startswith("eh_score_mfma_kernel") and k.endswith(f"grid {grid}")}
+    if not parts:
+        return None, None, os.path.relpath(files[-1], ROOT)
+    return sum(v["bytes_per_launch"] for v in parts.values()), {k: v["bytes_per_launch"] for k, v in parts.items()}, os.path.relpath(files[-1], ROOT)
+
+
 def kernel_counters(table, needle, per_call=False, kernel_ms=None):
     """per_call: counters summed over every launch of the kernel per full-size launch (a call of the dominant kernel may
     cut its last, nearly empty round off as a second small launch; the duration measured here covers both).
@@ -763,14 +783,21 @@ def run_c5(args, torch, dist, orc, _capi, ops, sharding, synthetic, world, rank,
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def progress(what, i, of):  # a step of this workload takes seconds: a line per step on stderr shows that the run is alive
+        if rank == 0:
+            print(f"[bench c5] {what} step {i + 1} of {of} submitted, {time.perf_counter() - t_start:.1f} s", file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
+    for i in range(args.warmup):
         step()
+        progress("warm-up", i, args.warmup)
     sync()
     for k in stats:
         stats[k] = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step()
+        progress("timed", i, args.steps)
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=key_device)
@@ -1096,6 +1123,7 @@ def main():
         cnt, ind = exact_winner
         ecnt, eind = ops.decode_best(eff_best.cpu().numpy())
         table, counters_file = load_profile_counters(n, B)
+        traffic, traffic_parts, traffic_file = load_traffic(n, B)
         bound_issue = issue_roofline(kern_ms, kernel_counters(table, "eh_upper_mfma_kernel<true, true", per_call=True))
         exact_issue = issue_roofline(mixed_ms, kernel_counters_sum(table, "eh_score_mfma_kernel", mixed_ms)
                                      or kernel_counters(table, "eh_score_mfma_kernel", kernel_ms=mixed_ms))
@@ -1110,9 +1138,13 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_VALU_TFLOPS,
             "frac_from_value": value / world * (FLOPS_PER_E_EVAL + FLOPS_PER_H_EVAL) / 2.0 / 1e12 / PEAK_FP32_VALU_TFLOPS,
-            "traffic": exact_issue.get("hbm_bytes_per_launch") if exact_issue else None,
-            "traffic_unit": "bytes per call (both launches): FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes of this command (the file "
-            "named in counters_from); algorithmic bytes are 48 MB of index sets + 0.3 MB of matches read, 8 MB of counts written",
+            "traffic": traffic,
+            "traffic_unit": "bytes per call (both launches): FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes over "
+            "profiles/tools/traffic_probe.py (this library call on this shape, one launch at a time; the file named in traffic_from).  Each of "
+            "the two launches reads the 48 MB of index rows (whole 128-byte lines are fetched although a model uses 32 or 16 of a row's 48 "
+            "bytes) and the 1 MB of matches once per XCD (8 L2s); 8 MB of counts are written",
+            "traffic_per_launch": traffic_parts,
+            "traffic_from": traffic_file,
             "counters_from": counters_file,
             "kernel_ms": mixed_ms,
             "definition": "achieved = 57 algorithmic flops (36 per symmetric-epipolar + 21 per transfer residual of the reference's formulas) x "

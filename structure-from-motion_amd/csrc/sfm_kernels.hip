@@ -690,13 +690,16 @@ __global__ __launch_bounds__(kBlock, 3) void eh_upper_mfma_kernel(const double4*
   // operands prepared for another threshold, or matches without a usable coordinate bound, cannot give valid bounds:
   // report the trivial bound (all matches of this split)
   if (*reinterpret_cast<const double*>(xy + npad_all) != inv_sqrt_k1 || !(xm < 1.0e6)) oute = outh = max(0, min(n, t1 * 32) - t0 * 32);
-  if (gid < nb) {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // the hypothesis id is formed again here rather than held in two registers across the tile loop
+  const long long out_id = (long long)blockIdx.x * blockDim.x + tid;
+  if (out_id < nb) {
     if (use_atomics) {
-      atomicAdd(up_e + gid, oute);
-      atomicAdd(up_h + gid, outh);
+      atomicAdd(up_e + out_id, oute);
+      atomicAdd(up_h + out_id, outh);
     } else {
-      up_e[gid] = oute;
-      up_h[gid] = outh;
+      up_e[out_id] = oute;
+      up_h[out_id] = outh;
     }
   }
 }
@@ -830,6 +833,15 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma_kernel(const
     if constexpr (kDoE) mstage[kModel * lane + i] = Ed[i];
     if constexpr (kDoH) mstage[kModel * lane + (kDoE ? 9 : 0) + i] = Hd[i];
   }
+  // E alone at three waves per SIMD is a dozen registers short: three of the piece vectors of the second hypothesis group
+  // stay in LDS behind the models (three 16-byte reads per tile) instead of being spilled to scratch memory by the compiler
+  constexpr bool kParkColumns = kDoE && !kDoH;
+  static_assert(!kParkColumns || kModel * 8 * 64 + 3 * 64 * 16 <= kVec * 32 * 64, "the parked vectors fit behind the models");
+  uint4* parked = reinterpret_cast<uint4*>(mstage + kModel * 64);
+  if constexpr (kParkColumns) {
+#pragma unroll
+    for (int v = 0; v < 3; ++v) parked[64 * v + lane] = __builtin_bit_cast(uint4, B[1][2 + v]);
+  }
   __syncthreads();
   const float rkf = (float)sqrt(two_thr_e2), rtf = (float)sqrt(thr_h2);
   const int apos = 16 * ((col >> 2) & 1) + (col & 3) + 4 * (col >> 3);  // see eh_upper_mfma_kernel
@@ -860,11 +872,21 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma_kernel(const
       unsigned amb_e = 0, amb_h = 0;
       if constexpr (kDoE) {
         const bf16x8 A2 = as_bf16x8(src[2]);
+        bf16x8 b2 = B[k][2], b3 = B[k][3], b4 = B[k][4];
+        if constexpr (kParkColumns) {
+          if (k == 1) {
+            int at = lane;
+            asm volatile("" : "+v"(at));  // keeps the reads inside the loop (hoisted, they would be spilled again)
+            b2 = as_bf16x8(parked[at]);
+            b3 = as_bf16x8(parked[64 + at]);
+            b4 = as_bf16x8(parked[128 + at]);
+          }
+        }
         const f32x16 l0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][0], zero, 0, 0, 0);
         const f32x16 l1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][1], zero, 0, 0, 0);
-        const f32x16 l2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[k][2], zero, 0, 0, 0);
-        const f32x16 m0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B[k][3], zero, 0, 0, 0);
-        const f32x16 m1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B[k][4], zero, 0, 0, 0);
+        const f32x16 l2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, b2, zero, 0, 0, 0);
+        const f32x16 m0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, b3, zero, 0, 0, 0);
+        const f32x16 m1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, b4, zero, 0, 0, 0);
         auto fE = [&](int i) {  // < 0 <=> inlier
           const float s = fma(l0[i], x2[i], fma(l1[i], y2[i], l2[i]));
           const float n1 = fma(l0[i], l0[i], l1[i] * l1[i]);
@@ -955,13 +977,16 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma_kernel(const
   }
   const unsigned ok = fin[wave][lane];
   const int oute = (ok & 1u) ? (half ? se[1] : se[0]) : 0, outh = (ok & 2u) ? (half ? sh[1] : sh[0]) : 0;
-  if (gid < nb) {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // the hypothesis id is formed again here: held across the tile loop it costs two registers (a spill at three waves)
+  const long long out_id = (long long)blockIdx.x * blockDim.x + tid;
+  if (out_id < nb) {
     if (use_atomics) {
-      if constexpr (kDoE) atomicAdd(count_e + gid, oute);
-      if constexpr (kDoH) atomicAdd(count_h + gid, outh);
+      if constexpr (kDoE) atomicAdd(count_e + out_id, oute);
+      if constexpr (kDoH) atomicAdd(count_h + out_id, outh);
     } else {
-      if constexpr (kDoE) count_e[gid] = oute;
-      if constexpr (kDoH) count_h[gid] = outh;
+      if constexpr (kDoE) count_e[out_id] = oute;
+      if constexpr (kDoH) count_h[out_id] = outh;
     }
   }
 }
