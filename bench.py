@@ -44,9 +44,9 @@ PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32
 PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector FP64 (half of the FP32 vector rate)
 SPEC_CLOCK_HZ = 2.4e9
 N_SIMD = 1024  # 256 CUs x 4
-# a pure v_fma_f32 stream on this chip under sustained load (kernels of 10+ ms, 4 waves per SIMD):
-# profiles/microbench/mfma_valu_overlap_mi355x.txt, row "M=0 MFMA N= 96 VALU waves/SIMD 4"
-SUSTAINED_NS_PER_VALU_INSTRUCTION = 19.903e6 / (4 * 40000 * 96)
+# a pure v_fma_f32 stream on this chip, 4 waves per SIMD, waves running to a common deadline: 2.04 cycles per instruction
+# per SIMD at a held clock of 2.02 GHz (profiles/microbench/valu_issue_probe_mi355x.txt, pattern 0, waves/SIMD 4)
+SUSTAINED_NS_PER_VALU_INSTRUCTION = 2.04 / 2.018
 
 
 def load_profile_counters(matches, hyps):
@@ -64,24 +64,28 @@ def load_profile_counters(matches, hyps):
         return json.load(f), os.path.relpath(files[-1], ROOT)
 
 
-def load_traffic(matches, hyps):
-    """Memory-side bytes per call of the exact E/H scorer on the default workload from the newest profiles/r*_traffic.json
-    (profiles/tools/traffic_probe.py: the same library call on the same shape, one launch at a time under separate
-    rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes): the sum over the launches one call makes."""
+def load_traffic():
+    """The newest profiles/r*_traffic.json (profiles/tools/traffic_probe.py: the scoring calls of the default workloads,
+    one launch at a time, under separate rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes): {kernel + grid: bytes}."""
     import glob
 
-    if (matches, hyps) != (10000, 1000000):
-        return None, None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
-        return None, None, None
+        return {}, None
     with open(files[-1]) as f:
-        t = json.load(f)
-    grid = (hyps + 255) // 256 * 256
-    parts = {k: v for k, v in t.items() if k.startswith("eh_score_mfma_kernel") and k.endswith(f"grid {grid}")}
-    if not parts:
-        return None, None, os.path.relpath(files[-1], ROOT)
-    return sum(v["bytes_per_launch"] for v in parts.values()), {k: v["bytes_per_launch"] for k, v in parts.items()}, os.path.relpath(files[-1], ROOT)
+        return json.load(f), os.path.relpath(files[-1], ROOT)
+
+
+def traffic_of(table, prefix, grid=None):
+    """Memory-side bytes per launch of the kernels whose name starts with prefix (at the given grid size, else the largest
+    profiled): (sum over the instantiations, {name: bytes})."""
+    rows = {k: v["bytes_per_launch"] for k, v in table.items() if k.startswith(prefix)}
+    if grid is not None:
+        rows = {k: v for k, v in rows.items() if k.endswith(f"grid {grid}")}
+    elif rows:
+        top = max(int(k.rsplit(" ", 1)[1]) for k in rows)
+        rows = {k: v for k, v in rows.items() if k.endswith(f"grid {top}")}
+    return (sum(rows.values()), rows) if rows else (None, None)
 
 
 def kernel_counters(table, needle, per_call=False, kernel_ms=None):
@@ -163,9 +167,6 @@ def issue_roofline(kernel_ms, c):
         out["mfma_pipe_busy_frac_at_spec_clock"] = c["SQ_INSTS_MFMA"] * 32.0 / (N_SIMD * SPEC_CLOCK_HZ * t)
     if "GRBM_GUI_ACTIVE" in c and c.get("GRBM_GUI_ACTIVE__dur_us"):
         out["clock_ghz_under_the_profiler"] = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["GRBM_GUI_ACTIVE__dur_us"] * 1e-6) / 1e9
-    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        # gfx950 tallies 128-byte read requests as 64 bytes: FETCH_SIZE is doubled; both counters are in KB
-        out["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
     return out
 
 
@@ -358,6 +359,10 @@ def secondary_measurements(torch, ops, _capi, synthetic, seed, table=None):
             "frac": FLOPS_PER_T_EVAL * ncam * float(m) * B / (ms_mixed * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
             "flops_per_eval": FLOPS_PER_T_EVAL,
             "issue": issue_roofline(ms_mixed, kernel_counters(table, "t_score_mfma_kernel", kernel_ms=ms_mixed)),
+            "traffic": traffic_of(load_traffic()[0], "t_score_mfma_kernel")[0],
+            "traffic_unit": "bytes per launch, FETCH_SIZE x2 + WRITE_SIZE (profiles/tools/traffic_probe.py on this workload): the index pairs are "
+            "read once per split of a camera's correspondence range (8 x 9.6 MB), the counts are added atomically once per split (38 MB), every XCD "
+            "gathers sample points from all cameras' float64 points (8 x 29 MB) and streams its eighth of the match-side pieces (58 MB)",
         },
     }
     # C4-like: LM (10 iterations, mu = 0.01) and triangulation with per-camera sizes 1e2..1e4
@@ -1123,10 +1128,14 @@ def main():
         cnt, ind = exact_winner
         ecnt, eind = ops.decode_best(eff_best.cpu().numpy())
         table, counters_file = load_profile_counters(n, B)
-        traffic, traffic_parts, traffic_file = load_traffic(n, B)
+        traffic_table, traffic_file = load_traffic()
+        default_shape = (n, B) == (10000, 1000000)
+        traffic, traffic_parts = traffic_of(traffic_table, "eh_score_mfma_kernel", (B + 255) // 256 * 256) if default_shape else (None, None)
         bound_issue = issue_roofline(kern_ms, kernel_counters(table, "eh_upper_mfma_kernel<true, true", per_call=True))
         exact_issue = issue_roofline(mixed_ms, kernel_counters_sum(table, "eh_score_mfma_kernel", mixed_ms)
                                      or kernel_counters(table, "eh_score_mfma_kernel", kernel_ms=mixed_ms))
+        if bound_issue is not None and default_shape:
+            bound_issue["memory_bytes_per_launch"] = traffic_of(traffic_table, "eh_upper_mfma_kernel<true, true, true>")[0]
         achieved = flops_per_launch / (mixed_ms * 1e-3) / 1e12
         roofline = {
             "bound": "valu_fp32",

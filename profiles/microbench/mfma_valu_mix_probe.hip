@@ -57,6 +57,79 @@ __global__ __launch_bounds__(1024) void k(Rec* out, const uint4* __restrict__ in
   if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = Rec{iters, t1 - t0, r1 - r0};
 }
 
+// The same measurement with the MFMAs in three accumulation chains of C0, C1 and C2 instructions (each chain adds into one
+// accumulator: a K = 16 C contraction), followed by N v_fma_f32 that read the three accumulators: the shape of a test whose
+// bilinear and quadratic forms come whole from the matrix cores.
+template <int C0, int C1, int C2, int N>
+__global__ __launch_bounds__(1024) void kchain(Rec* out, const uint4* __restrict__ in, unsigned long long ticks) {
+  const uint4 ua = in[threadIdx.x & 255], ub = in[256 + (threadIdx.x & 255)];
+  // every MFMA gets operand registers of its own (equal values, but the compiler cannot know: equal operands would let it
+  // merge the chains)
+  bf16x8 a[3][4], b[3][4];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      a[c][m] = __builtin_bit_cast(bf16x8, ua);
+      b[c][m] = __builtin_bit_cast(bf16x8, ub);
+      asm volatile("" : "+v"(a[c][m]), "+v"(b[c][m]));
+    }
+  float x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = __uint_as_float(ua.x) * (i + 1);
+  const float c0 = __uint_as_float(ub.y);
+  const f32x16 zero = {0};
+  f32x16 acc[3] = {zero, zero, zero};
+  __syncthreads();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long deadline = r0 + ticks;
+  unsigned long long iters = 0, r1 = r0;
+  constexpr int CH[3] = {C0, C1, C2};
+  while (r1 < deadline) {
+#pragma unroll 1
+    for (int rep = 0; rep < 4; ++rep) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int m = 0; m < CH[c]; ++m) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c][m], b[c][m], m == 0 ? zero : acc[c], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const float av = acc[j % 3][(j / 3) % 16];
+        asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x[j % 16]) : "v"(av), "v"(c0), "v"(x[(j + 8) % 16]));
+      }
+    }
+    iters += 4;
+    r1 = __builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float r = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r += x[i];
+  if (r == 12345.678f) out[0].iters = 1;
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = Rec{iters, t1 - t0, r1 - r0};
+}
+
+template <int C0, int C1, int C2, int N>
+int run_chain(int w, const uint4* in, Rec* out) {
+  const int blocks = 256, threads = 256 * w, waves = blocks * threads / 64;
+  kchain<C0, C1, C2, N><<<blocks, threads>>>(out, in, 100000ull * 300);
+  CHECK(hipDeviceSynchronize());
+  std::vector<Rec> h(waves);
+  CHECK(hipMemcpy(h.data(), out, sizeof(Rec) * waves, hipMemcpyDeviceToHost));
+  double it = 0, cyc = 0;
+  std::vector<double> clk;
+  for (auto& r : h) { it += (double)r.iters; cyc += (double)r.cycles; clk.push_back((double)r.cycles / (double)r.ticks * 0.1); }
+  std::sort(clk.begin(), clk.end());
+  const double per_simd_it = it / 1024.0, mean_cyc = cyc / waves;
+  constexpr int M = C0 + C1 + C2;
+  printf("chains %d+%d+%d MFMA + N=%3d v_fma (VOP3)  waves/SIMD %d: %7.1f cycles per iteration per SIMD (issue bound %4d = %.2f of it; matrix pipe %4d = %.2f of it), held clock %.3f GHz\n",
+         C0, C1, C2, N, w, mean_cyc / per_simd_it, 2 * N + 8 * M, (2 * N + 8 * M) / (mean_cyc / per_simd_it), 32 * M, 32 * M / (mean_cyc / per_simd_it), clk[clk.size() / 2]);
+  fflush(stdout);
+  return 0;
+}
+
 template <int M, int N, int ENC>
 int run(int w, const uint4* in, Rec* out) {
   const int blocks = 256, threads = 256 * w, waves = blocks * threads / 64;
@@ -76,7 +149,7 @@ int run(int w, const uint4* in, Rec* out) {
   return 0;
 }
 
-int main() {
+int main(int argc, char**) {
   uint4* in; Rec* out;
   CHECK(hipMalloc(&in, sizeof(uint4) * 512));
   CHECK(hipMalloc(&out, sizeof(Rec) * 256 * 16));
@@ -88,6 +161,18 @@ int main() {
     v = lo | (hi << 16);
   }
   CHECK(hipMemcpy(in, h.data(), 8192, hipMemcpyHostToDevice));
+  if (argc > 1) {  // the chained shapes only
+    for (int w : {2, 3, 4}) {
+      if (run_chain<4, 1, 1, 160>(w, in, out)) return 1;
+      if (run_chain<4, 2, 2, 160>(w, in, out)) return 1;
+      if (run_chain<4, 3, 3, 160>(w, in, out)) return 1;
+      if (run_chain<1, 1, 1, 288>(w, in, out)) return 1;
+      if (run_chain<1, 1, 2, 128>(w, in, out)) return 1;
+      if (run_chain<3, 3, 1, 96>(w, in, out)) return 1;
+      if (run_chain<1, 1, 1, 144>(w, in, out)) return 1;
+    }
+    return 0;
+  }
   for (int w : {2, 3, 4}) {
     if (run<3, 96, 2>(w, in, out)) return 1;
     if (run<3, 96, 3>(w, in, out)) return 1;

@@ -15,6 +15,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -66,7 +67,7 @@ def collect(fetch_dir, write_dir, out):
                 name = r["Kernel_Name"]
                 if r["Counter_Name"] != key or "mfma_kernel" not in name or "corr_to" in name or "t_prep" in name:
                     continue
-                short = name.split("(anonymous namespace)::")[-1].split("(")[0]
+                short = re.search(r"(\w+_kernel(<[^>]*>)?)", name).group(1)
                 table.setdefault(f"{short} grid {r['Grid_Size']}", {}).setdefault(key, []).append(float(r["Counter_Value"]))
     res = {}
     for k, c in table.items():

@@ -55,8 +55,12 @@ def image_features(img_path, mode):
     (src/utils.py:78-80)."""
     if mode not in ("bgr2gray", "grayscale"):
         raise ValueError(mode)
-    # the two read modes only differ inside OpenCV's decoders; every other decoder gives one gray image per file
-    key = (os.path.abspath(img_path), mode if os.environ.get("SFM_HIP_SIFT", "hip") == "cv2" else "gray")
+    # the two read modes only differ inside OpenCV's decoders (whichever detector then runs on the image); Pillow gives one
+    # gray image per file, and only then do the two modes share their features
+    from . import sift
+
+    per_mode = os.environ.get("SFM_HIP_SIFT", "hip") == "cv2" or sift.read_modes_differ()
+    key = (os.path.abspath(img_path), mode if per_mode else "gray")
     if key in _features:
         return _features[key]
     cache = None

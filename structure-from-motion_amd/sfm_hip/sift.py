@@ -110,6 +110,16 @@ def gaussian_taps(sigma):
     return taps[: n.value].copy()
 
 
+def read_modes_differ():
+    """True when read_gray decodes with OpenCV: its two read modes may give images that differ in the last bit (colour
+    conversion before or after the decoder's own), so features are then kept per (file, mode); Pillow gives one image."""
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        return False
+    return True
+
+
 def read_gray(img_path, mode):
     """The grayscale image the reference feeds to SIFT.  mode "bgr2gray": cv2.imread + cvtColor(BGR2GRAY)
     (src/extract_sift.py:104-107); mode "grayscale": cv2.imread(IMREAD_GRAYSCALE) (src/utils.py:78).  Uses OpenCV when
