@@ -87,6 +87,7 @@ def measure(name, fn, pairs_per_tile_wave, valu_per_tile, mfma_per_tile):
            "share_of_time_with_k_waves_of_a_simd_in_the_tile_loop": [round(float(h), 3) for h in hist[:6]],
            "solve_phase_us_median": round(float(np.median((raw[:, 3] - raw[:, 6]).astype(np.float64))) * 1e-2, 2),
            "tile_loop_us_median": round(float(np.median((raw[:, 4] - raw[:, 3]).astype(np.float64))) * 1e-2, 2),
+           "counted_lanes_per_wave_and_tile_mean": round(float(raw[:, 7].sum()) / max(1.0, float(raw[:, 2].sum())), 4),
            "pairs_per_tile_and_wave": pairs_per_tile_wave, "valu_instructions_per_tile_and_wave": valu_per_tile, "mfma_per_tile_and_wave": mfma_per_tile}
     print(json.dumps(out), flush=True)
     return out

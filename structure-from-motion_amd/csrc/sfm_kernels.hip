@@ -30,11 +30,14 @@ constexpr int kMaxCams = 64;
 // matrix-core kernels stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around its tile loop into a buffer
 // of its own that no kernel reads; sfm_debug_clock_stamps copies it out.  held clock = cycles / ticks x 100 MHz.
 // A record is 8 x uint64: cycles, ticks, tiles walked, start tick, end tick, (XCC_ID << 32) | HW_ID of the wave, the tick at
-// which the wave entered the kernel, 0.
+// which the wave entered the kernel, a count kept with SFM_STAMP_COUNT (lanes for which a condition held).
 #ifdef SFM_CLOCK_STAMPS
 constexpr int kStampSlots = 16384;
 __device__ unsigned long long g_stamps[kStampSlots * 8];
-#define SFM_STAMP_ENTRY() const unsigned long long stamp_entry_ = __builtin_amdgcn_s_memrealtime()
+#define SFM_STAMP_ENTRY()                                                        \
+  const unsigned long long stamp_entry_ = __builtin_amdgcn_s_memrealtime(); \
+  unsigned long long stamp_count_ = 0
+#define SFM_STAMP_COUNT(cond) stamp_count_ += __popcll(__ballot(cond))
 #define SFM_STAMP_BEGIN()                                                   \
   const unsigned long long stamp_r0_ = __builtin_amdgcn_s_memrealtime(); \
   const unsigned long long stamp_t0_ = __builtin_amdgcn_s_memtime()
@@ -52,11 +55,12 @@ __device__ unsigned long long g_stamps[kStampSlots * 8];
       dst_[4] = stamp_r1_;                                                                                                      \
       dst_[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4); \
       dst_[6] = stamp_entry_;                                                                                                   \
-      dst_[7] = 0;                                                                                                              \
+      dst_[7] = stamp_count_;                                                                                                   \
     }                                                                                                                           \
   } while (0)
 #else
 #define SFM_STAMP_ENTRY() do { } while (0)
+#define SFM_STAMP_COUNT(cond) do { } while (0)
 #define SFM_STAMP_BEGIN() do { } while (0)
 #define SFM_STAMP_END(units) do { } while (0)
 #endif
@@ -467,6 +471,13 @@ __device__ __forceinline__ unsigned tile_tail_mask(int n, int half) {
 __device__ __forceinline__ float min3_abs(float m, float a, float b) {
   float r;
   asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
+}
+
+// min(m, a, b) in one instruction; a NaN operand is ignored, as by fminf
+__device__ __forceinline__ float min3_f32(float m, float a, float b) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
   return r;
 }
 
@@ -979,6 +990,404 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma_kernel(const
   const int oute = (ok & 1u) ? (half ? se[1] : se[0]) : 0, outh = (ok & 2u) ? (half ? sh[1] : sh[0]) : 0;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));  // the hypothesis id is formed again here: held across the tile loop it costs two registers (a spill at three waves)
+  const long long out_id = (long long)blockIdx.x * blockDim.x + tid;
+  if (out_id < nb) {
+    if (use_atomics) {
+      if constexpr (kDoE) atomicAdd(count_e + out_id, oute);
+      if constexpr (kDoH) atomicAdd(count_h + out_id, outh);
+    } else {
+      if constexpr (kDoE) count_e[out_id] = oute;
+      if constexpr (kDoH) count_h[out_id] = outh;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// The same exact counts with the WHOLE epipolar test on the matrix cores' outputs.  The float64 test of eh_score_kernel is
+//     s^2 (n1 + n2) < k n1 n2,   s = x2^T E x1,  n1 = |(E x1)_{0,1}|^2,  n2 = |(E^T x2)_{0,1}|^2,  k = 2 thr^2,
+// and s is a bilinear form in (x1, x2), n1 and n2 are quadratic forms in x1 and in x2: all three are contractions of
+// match-side monomials with hypothesis-side coefficients, so they come out of chained bf16 MFMAs
+//     s   = [x2 x1, x2 y1] . [E00, E01] + [y2 x1, y2 y1] . [E10, E11] + [x2, y2, 1] . [E02, E12, 0] + [x1, y1, 1] . [E20, E21, E22]
+//     n1' = k n1 = [x1^2, x1 y1, y1^2] . k [Qaa, Qab, Qbb] + [x1, y1, 1] . k [Qa, Qb, Q1]          (Q = coefficients of |(E x1)_{0,1}|^2)
+//     n2  =        [x2^2, x2 y2, y2^2] . [...]            + [x2, y2, 1] . [...]
+// (4 + 2 + 2 MFMAs per 32 x 32 pairs; monomials and coefficients are formed in float64 and split into three bf16 pieces;
+// the products of the quadratic monomials keep 5 of the 9 piece products, relative error 2^-17, which is ample: the norms
+// enter the test scaled by k).  The vector ALU is left with
+//     D = s^2 (n1'/k + n2) - n1' n2      (4 instructions; < 0 <=> inlier)      and the band      |D| <= S (A |s| + B) + C s^2 + T
+// (3 instructions + half a v_min3), 10 issue slots per pair with the sign history instead of 18.
+// Error bound (everything relative to the float64 value of D on the unrounded inputs; u = 2^-24):
+//   |s_c - s| <= es = (2 + 32*4) u Sb   (piece expansion + accumulation of a 4-MFMA chain in any order, Sb >= sum |E||x2||x1|),
+//   |n_c - n| <= en = (2^-17 + 66 u) Nb (Nb >= sum |Q||monomial|), eS = en1 + en2,
+//   |s_c^2 S_c - s^2 S| <= s_c^2 eS + (2 |s_c| es + es^2)(S_c + eS),   |P_c - k n1 n2| <= k (S_c + eS) en + k en^2,
+//   float32 evaluation of D: 4.1 u s_c^2 S_c + u P_c <= 4.1 u Sb |s_c| S_c + u k Lb2 S_c,  Lb2 >= min(n1, n2),
+// collected (with 2 |s_c| es eS <= (s_c^2 + es^2) eS) as A = 2 es + 4.1 u (Sb + es), B = 3 es^2 + k en + u k Lb2, C = 2 eS,
+// T = the products of three error terms + an absolute floor, all doubled (safety) and rounded up.
+// ---------------------------------------------------------------------------------------
+constexpr int kEhxVecA = 6;  // match-side vectors per match: Sa, Sb, Q1, Q2, A1 = (x1, y1, 1), A2 = (x2, y2, 1)
+
+// 5-term piece products of three monomials: hypothesis side (q0 q0 q1 q0 q2), match side (m0 m1 m0 m2 m0), 15 of 16 slots
+__device__ __forceinline__ void pack_quad(double a, double b, double c, bool model, uint4& lo, uint4& hi) {
+  unsigned p[3][3];
+  split3_bf16(a, p[0]);
+  split3_bf16(b, p[1]);
+  split3_bf16(c, p[2]);
+  unsigned e[16];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    if (model) {
+      e[5 * m] = p[m][0]; e[5 * m + 1] = p[m][0]; e[5 * m + 2] = p[m][1]; e[5 * m + 3] = p[m][0]; e[5 * m + 4] = p[m][2];
+    } else {
+      e[5 * m] = p[m][0]; e[5 * m + 1] = p[m][1]; e[5 * m + 2] = p[m][0]; e[5 * m + 3] = p[m][2]; e[5 * m + 4] = p[m][0];
+    }
+  }
+  e[15] = 0;
+  lo = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+  hi = make_uint4(e[8] | (e[9] << 16), e[10] | (e[11] << 16), e[12] | (e[13] << 16), e[14] | (e[15] << 16));
+}
+
+// pieces[tile][vector][match of the tile][half]: a wave's load of one vector of one tile is 1 KB of consecutive bytes
+__global__ __launch_bounds__(kBlock) void corr_to_mfma3_kernel(const double4* __restrict__ corr, int n, int npad, uint4* __restrict__ pieces,
+                                                               float2* __restrict__ xy) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  double4 c = make_double4(0.0, 0.0, 0.0, 0.0);
+  if (j < npad) {
+    uint4* out = pieces + ((long long)(j >> 5) * (kEhxVecA * 32) + (j & 31)) * 2;  // vector v at out[64 v], out[64 v + 1]
+    if (j < n) {
+      c = corr[j];
+      pack_pieces(c.z * c.x, c.z * c.y, 1.0, false, out[0], out[1]);
+      pack_pieces(c.w * c.x, c.w * c.y, 1.0, false, out[64], out[65]);
+      pack_quad(c.x * c.x, c.x * c.y, c.y * c.y, false, out[128], out[129]);
+      pack_quad(c.z * c.z, c.z * c.w, c.w * c.w, false, out[192], out[193]);
+      pack_pieces(c.x, c.y, 1.0, false, out[256], out[257]);
+      pack_pieces(c.z, c.w, 1.0, false, out[320], out[321]);
+      xy[j] = make_float2((float)c.z, (float)c.w);
+    } else {
+#pragma unroll
+      for (int v = 0; v < kEhxVecA; ++v) out[64 * v] = out[64 * v + 1] = make_uint4(0, 0, 0, 0);
+      xy[j] = make_float2(0.0f, 0.0f);
+    }
+  }
+  publish_absmax(c, j < n, reinterpret_cast<unsigned*>(xy + npad));  // 16-byte trailer, zeroed by the launcher
+}
+
+template <bool kDoE, bool kDoH, int kMinBlocks>
+__global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
+                                                                            const float2* __restrict__ xy, int n,
+                                                                            const int32_t* __restrict__ idx, long long nb, double two_thr_e2,
+                                                                            double thr_h2, double xmax, int* __restrict__ count_e,
+                                                                            int* __restrict__ count_h, int tiles_per_split, int use_atomics) {
+  constexpr int kModel = 9 * ((kDoE ? 1 : 0) + (kDoH ? 1 : 0));  // doubles per hypothesis parked for the float64 re-evaluation
+  constexpr bool kPark = kDoE != kDoH;          // a one-model instantiation keeps some piece vectors in LDS, see below
+  constexpr int kParked = kPark ? (kDoE ? 3 : 4) : 0;
+  constexpr int kAfter = kModel * 8 * 64 + kParked * 16 * 64;  // the staging area later holds the float64 models and the parked vectors
+  constexpr int kStageBytes = kAfter > 4 * 32 * 64 ? kAfter : 4 * 32 * 64;  // four piece vectors per round first
+  constexpr int kQueue = 256;  // pairs whose float32 sign is not trusted wait here for a dense float64 pass (per wave)
+  __shared__ unsigned char fin[kBlock / 64][64];
+  __shared__ __align__(16) unsigned char stage_raw[kBlock / 64][kStageBytes];
+  __shared__ unsigned qbuf[kBlock / 64][kQueue];
+  __shared__ int qcnt[kBlock / 64][(kDoE && kDoH) ? 2 : 1][64];
+  SFM_STAMP_ENTRY();
+  __builtin_amdgcn_s_setprio(3);  // the solve runs ahead of the other waves' tile loops (see eh_upper_mfma_kernel)
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long hyp = gid < nb ? gid : nb - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const double safety = 2.0;
+  const double xm = usable_xmax(xmax, *reinterpret_cast<const unsigned*>(xy + ((n + 31) / 32) * 32));
+  const bool all_f64 = !(xm < 1.0e4);  // no usable coordinate bound (or float32 products that could overflow): every pair takes the float64 test
+  uint4(*bstage)[4][2] = reinterpret_cast<uint4(*)[4][2]>(&stage_raw[wave][0]);  // [lane][vector of the round][half]
+  double Ed[9], Hd[9];
+  float ea_own = 0.0f, eb_own = 0.0f, ec_own = 0.0f, gh_own = 0.0f;
+  bf16x8 BE[2][kDoE ? 8 : 1], BH[2][kDoH ? 3 : 1];
+  {
+    double p8[8][4], p4[4][4];
+    gather_samples<double>(corr, n, idx + 12 * hyp, p8, p4);
+    if constexpr (kDoE) solve_E8<double>(p8, Ed);
+    if constexpr (kDoH) solve_H4<double>(p4, Hd);
+  }
+  {
+    double chk_e = 0.0, chk_h = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      if constexpr (kDoE) chk_e = fma(Ed[i], 0.0, chk_e);
+      if constexpr (kDoH) chk_h = fma(Hd[i], 0.0, chk_h);
+    }
+    fin[wave][lane] = (unsigned char)((chk_e == 0.0 ? 1 : 0) | (chk_h == 0.0 ? 2 : 0));
+  }
+  auto fetch_round = [&](auto& B, int first, int count) {  // piece vectors first .. first + count - 1 of both hypothesis groups
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int v = 0; v < count; ++v) B[k][first + v] = as_bf16x8(bstage[32 * k + col][v][half]);
+    __syncthreads();
+  };
+  if constexpr (kDoE) {
+    double A[9], e[9], n2_offset;
+    float unused[9];
+    const double inv = to_unit_f32(Ed, unused, A);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) e[i] = Ed[i] * inv;
+    const double k = two_thr_e2;
+    const double R0 = xm * (A[0] + A[1]) + A[2], R1 = xm * (A[3] + A[4]) + A[5], R2 = xm * (A[6] + A[7]) + A[8];
+    const double C0 = xm * (A[0] + A[3]) + A[6], C1 = xm * (A[1] + A[4]) + A[7];
+    const double Sb = xm * (R0 + R1) + R2, N1b = R0 * R0 + R1 * R1, N2b = C0 * C0 + C1 * C1, Lb2 = fmin(N1b, N2b);
+    const double u = kEps32;
+    const double es = (2.0 + 32.0 * 4.0) * u * Sb;
+    const double kn = 0x1.1p-18 + 66.0 * u;
+    const double eS = kn * (N1b + N2b) * 1.0001;  // en1 + en2, the offset 2 eS of n2 (below) included in its bound
+    const double cA = 2.0 * es + 3.1 * u * (Sb + es);
+    const double cB = es * es + 6.0 * k * eS + u * k * (Lb2 + 4.0 * eS);
+    const double cC = 3.0 * eS;
+    const double infl = safety * (1.0 + 0x1.0p-18);
+    ea_own = round_up_f32(cA * infl);
+    eb_own = round_up_f32(cB * infl);
+    ec_own = round_up_f32(cC * infl);
+    n2_offset = 2.0 * eS;
+    // round 1: the four vectors of s
+    pack_pieces(e[0], e[1], 0.0, true, bstage[lane][0][0], bstage[lane][0][1]);
+    pack_pieces(e[3], e[4], 0.0, true, bstage[lane][1][0], bstage[lane][1][1]);
+    pack_pieces(e[2], e[5], 0.0, true, bstage[lane][2][0], bstage[lane][2][1]);
+    pack_pieces(e[6], e[7], e[8], true, bstage[lane][3][0], bstage[lane][3][1]);
+    fetch_round(BE, 0, 4);
+    // round 2: k n1 (quadratic and linear part), n2 (quadratic and linear part)
+    pack_quad(k * fma(e[0], e[0], e[3] * e[3]), 2.0 * k * fma(e[0], e[1], e[3] * e[4]), k * fma(e[1], e[1], e[4] * e[4]), true, bstage[lane][0][0],
+              bstage[lane][0][1]);
+    pack_pieces(2.0 * k * fma(e[0], e[2], e[3] * e[5]), 2.0 * k * fma(e[1], e[2], e[4] * e[5]), k * fma(e[2], e[2], e[5] * e[5]), true,
+                bstage[lane][1][0], bstage[lane][1][1]);
+    pack_quad(fma(e[0], e[0], e[1] * e[1]), 2.0 * fma(e[0], e[3], e[1] * e[4]), fma(e[3], e[3], e[4] * e[4]), true, bstage[lane][2][0],
+              bstage[lane][2][1]);
+    pack_pieces(2.0 * fma(e[0], e[6], e[1] * e[7]), 2.0 * fma(e[3], e[6], e[4] * e[7]), fma(e[6], e[6], e[7] * e[7]) + n2_offset, true,
+                bstage[lane][3][0], bstage[lane][3][1]);
+    fetch_round(BE, 4, 4);
+  }
+  if constexpr (kDoH) {
+    double A[9];
+    float unused[9];
+    const double inv = to_unit_f32(Hd, unused, A);
+    const double R0 = xm * (A[0] + A[1]) + A[2], R1 = xm * (A[3] + A[4]) + A[5], R2 = xm * (A[6] + A[7]) + A[8];
+    const double rt = sqrt(thr_h2);
+    const double Dx = (kEpsMfma + 3.0 * kEps32) * (R0 + xm * R2), Dy = (kEpsMfma + 3.0 * kEps32) * (R1 + xm * R2);
+    const double eq = rt * (kEpsMfma + 2.0 * kEps32) * R2;
+    const double e = safety * (Dx + Dy + eq);
+    // |dH_c| of a pair that the float32 sign may get wrong is below (4 e + 13 eps Q) |q_c| + 4.1 e^2 with |q_c| <= Q + e, Q = sqrt(T) R2
+    const double Q = rt * R2, c1 = 4.0 * e + 13.0 * kEps32 * Q * 1.001;
+    gh_own = !(xm < 1.0e5) ? __builtin_inff() : round_up_f32((c1 * (Q * 1.000001 + e) + 4.1 * e * e) * 1.000001);
+#pragma unroll
+    for (int v = 0; v < 3; ++v) pack_pieces(Hd[3 * v] * inv, Hd[3 * v + 1] * inv, Hd[3 * v + 2] * inv, true, bstage[lane][v][0], bstage[lane][v][1]);
+    fetch_round(BH, 0, 3);
+  }
+  float ea[2], eb[2], ec[2], gh[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    ea[k] = __shfl(ea_own, 32 * k + col);
+    eb[k] = __shfl(eb_own, 32 * k + col);
+    ec[k] = __shfl(ec_own, 32 * k + col);
+    gh[k] = __shfl(gh_own, 32 * k + col);
+  }
+  qcnt[wave][0][lane] = 0;
+  if constexpr (kDoE && kDoH) qcnt[wave][1][lane] = 0;
+  // The one-model instantiations (E at three, H at four waves per SIMD) are a dozen registers short: three (E) or four (H) piece vectors
+  // stay in LDS behind the models (16-byte reads per tile) instead of being spilled to
+  // scratch memory by the compiler
+
+  uint4* parked = reinterpret_cast<uint4*>(&stage_raw[wave][kModel * 8 * 64]);
+  // the staging area now holds the float64 models (in the solver's own scale) for the re-evaluation of pairs inside a band
+  double* mstage = reinterpret_cast<double*>(&stage_raw[wave][0]);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    if constexpr (kDoE) mstage[kModel * lane + i] = Ed[i];
+    if constexpr (kDoH) mstage[kModel * lane + (kDoE ? 9 : 0) + i] = Hd[i];
+  }
+  if constexpr (kPark) {
+#pragma unroll
+    for (int v = 0; v < 3; ++v) parked[64 * v + lane] = __builtin_bit_cast(uint4, kDoE ? BE[1][kDoE ? 5 + v : 0] : BH[1][kDoH ? v : 0]);
+    if constexpr (kDoH) parked[64 * 3 + lane] = __builtin_bit_cast(uint4, BH[0][kDoH ? 2 : 0]);
+  }
+  __syncthreads();
+  const float kinv = (float)(1.0 / two_thr_e2), rtf = (float)sqrt(thr_h2);
+  const int apos = 16 * ((col >> 2) & 1) + (col & 3) + 4 * (col >> 3);  // see eh_upper_mfma_kernel
+  const int ntiles = (n + 31) / 32;
+  const int t0 = blockIdx.y * tiles_per_split;
+  const int t1 = min(ntiles, t0 + tiles_per_split);
+  int ce[2] = {0, 0}, ch[2] = {0, 0};
+  const f32x16 zero = {0};
+  const unsigned tail_mask = tile_tail_mask(n, half);
+  const uint4* src = pieces + ((long long)t0 * (kEhxVecA * 32) + apos) * 2 + half;
+  const float4* xsrc = reinterpret_cast<const float4*>(xy + t0 * 32 + 16 * half);
+  // Pairs inside a band are not evaluated where they are found (a lane or two of a wave at a time, with the other lanes idle,
+  // on about half of all rows): their (match, hypothesis) ids are appended to a queue of the wave, and the queue is
+  // worked off 64 pairs at a time with the float64 tests of eh_score_kernel; the verdicts are added to per-hypothesis
+  // counters in LDS.  entry = match << 7 | test << 6 | hypothesis of the wave.
+  int qlen = 0;
+  auto drain = [&]() {
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < qlen; base += 64) {
+      if (base + lane < qlen) {
+        const unsigned e = qbuf[wave][base + lane];
+        const int h = (int)(e & 63u), test_h = kDoE ? (kDoH ? (int)((e >> 6) & 1u) : 0) : 1;
+        const double* M = mstage + kModel * h + ((kDoE && test_h) ? 9 : 0);
+        double Mm[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Mm[i] = M[i];
+        const double4 p = corr[e >> 7];
+        bool in;
+        if (test_h)
+          in = transfer_inlier<double>(Mm, p.x, p.y, p.z, p.w, thr_h2);
+        else
+          in = epipolar_inlier<double>(Mm, p.x, p.y, p.z, p.w, two_thr_e2);
+        if (in) atomicAdd(&qcnt[wave][(kDoE && kDoH) ? test_h : 0][h], 1);
+      }
+    }
+    qlen = 0;
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto enqueue = [&](unsigned amb, int hyp_of_wave, int test_h, int first_match) {  // called by the whole wave; bit 15-i of amb = match first_match + i
+    unsigned long long any = __ballot(amb != 0u);
+    while (any) {
+      const bool act = amb != 0u;
+      const int bit = __ffs((int)amb) - 1;
+      amb &= amb - 1u;
+      const unsigned entry = ((unsigned)(first_match + 15 - bit) << 7) | ((unsigned)test_h << 6) | (unsigned)hyp_of_wave;
+      const int pos = qlen + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(any >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)any, 0u));
+      if (act) qbuf[wave][pos] = entry;
+      qlen += __popcll(any);
+      if (qlen > kQueue - 64) drain();
+      any = __ballot(amb != 0u);
+    }
+  };
+  __builtin_amdgcn_s_setprio(0);
+  SFM_STAMP_BEGIN();
+  // The match-side vectors of a tile are loaded one tile ahead: after the last MFMA of a tile has been issued their
+  // registers are free, and the loads of the next tile then run under the vector work of the second hypothesis group.
+  bf16x8 A1, ASa, ASb, AQ1, AQ2, A2;
+  auto load_tile = [&](const uint4* q) {
+    A1 = as_bf16x8(q[4 * 64]);
+    if constexpr (kDoE) {
+      ASa = as_bf16x8(q[0]);
+      ASb = as_bf16x8(q[64]);
+      AQ1 = as_bf16x8(q[2 * 64]);
+      AQ2 = as_bf16x8(q[3 * 64]);
+      A2 = as_bf16x8(q[5 * 64]);
+    }
+  };
+  if (t0 < t1) load_tile(src);
+  for (int t = t0; t < t1; ++t, xsrc += 16) {
+    const unsigned vmask = t == (n >> 5) ? tail_mask : 0xFFFFu;
+    if (t + 1 < t1) src += kEhxVecA * 64;  // the last tile loads itself again
+    float x2[kDoH ? 16 : 1], y2[kDoH ? 16 : 1];
+    if constexpr (kDoH) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 v = xsrc[i];
+        x2[2 * i] = v.x; y2[2 * i] = v.y; x2[2 * i + 1] = v.z; y2[2 * i + 1] = v.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      unsigned amb_e = 0, amb_h = 0;
+      if constexpr (kDoE) {
+        bf16x8 b5 = BE[k][5], b6 = BE[k][6], b7 = BE[k][7];
+        if constexpr (kPark) {
+          if (k == 1) {
+            int at = lane;
+            asm volatile("" : "+v"(at));  // keeps the reads inside the loop (hoisted, they would be spilled again)
+            b5 = as_bf16x8(parked[at]);
+            b6 = as_bf16x8(parked[64 + at]);
+            b7 = as_bf16x8(parked[128 + at]);
+          }
+        }
+        f32x16 sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ASa, BE[k][0], zero, 0, 0, 0);
+        f32x16 n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ1, BE[k][4], zero, 0, 0, 0);
+        f32x16 n2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ2, b6, zero, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ASb, BE[k][1], sv, 0, 0, 0);
+        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, b5, n1, 0, 0, 0);
+        n2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, b7, n2, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, BE[k][2], sv, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, BE[k][3], sv, 0, 0, 0);
+        if constexpr (!kDoH) {
+          if (k == 1) load_tile(src);
+        }
+        unsigned hneg = 0, hamb = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float s2 = sv[i] * sv[i];
+          const float S = fma(n1[i], kinv, n2[i]);  // n1 comes as k n1, n2 with its offset: S >= the true n1 + n2 + eS
+          const float P = n1[i] * n2[i];
+          const float dv = fma(s2, S, -P);  // < 0 <=> inlier
+          const float w = fma(fabsf(sv[i]), ea[k], eb[k]);
+          const float rv = fma(-ec[k], s2, fma(-S, w, fabsf(dv)));  // < 0 <=> the float32 sign of dv is not trusted
+          hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(dv), 31);
+          hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(rv), 31);
+        }
+        amb_e = all_f64 ? vmask : (hamb & vmask);  // padding has dv = rv = -0 or +0: masked either way
+        ce[k] += __popc(hneg & vmask & ~amb_e);
+      }
+      if constexpr (kDoH) {
+        bf16x8 h0 = BH[k][0], h1 = BH[k][1], h2 = BH[k][2];
+        if constexpr (kPark) {
+          int at = lane;
+          asm volatile("" : "+v"(at));
+          if (k == 1) {
+            h0 = as_bf16x8(parked[at]);
+            h1 = as_bf16x8(parked[64 + at]);
+            h2 = as_bf16x8(parked[128 + at]);
+          } else {
+            h2 = as_bf16x8(parked[192 + at]);
+          }
+        }
+        const f32x16 hx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, h0, zero, 0, 0, 0);
+        const f32x16 hy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, h1, zero, 0, 0, 0);
+        const f32x16 hz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, h2, zero, 0, 0, 0);
+        if (k == 1) load_tile(src);
+        auto dH = [&](int i) {  // < 0 <=> inlier
+          const float dx = fma(x2[i], hz[i], -hx[i]);
+          const float dy = fma(y2[i], hz[i], -hy[i]);
+          const float q = rtf * hz[i];
+          return fma(-q, q, fma(dy, dy, dx * dx));
+        };
+        // the band is one constant per hypothesis: the loop keeps the smallest |dH| of the row (half a v_min3 per pair) and
+        // only a wave in which some row trips the band looks for the pairs (all its lanes walk that block: no lane waits)
+        unsigned hneg = 0;
+        float closest = __builtin_inff();
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          const float d0 = dH(i), d1 = dH(i + 1);
+          hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d0), 31);
+          hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d1), 31);
+          closest = min3_abs(closest, d0, d1);
+        }
+        ch[k] += __popc(hneg & vmask);
+        if (__ballot(closest <= gh[k])) {
+          unsigned hamb = 0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(dH(i)) - gh[k]), 31);  // the same values again
+          amb_h = !(xm < 1.0e5) ? vmask : (hamb & vmask);
+          ch[k] -= __popc(hneg & amb_h);  // take the untrusted signs back out
+        }
+      }
+      SFM_STAMP_COUNT((amb_e | amb_h) != 0u);
+      if constexpr (kDoE) {
+        if (__ballot(amb_e != 0u)) enqueue(amb_e, 32 * k + col, 0, t * 32 + 16 * half);
+      }
+      if constexpr (kDoH) {
+        if (__ballot(amb_h != 0u)) enqueue(amb_h, 32 * k + col, 1, t * 32 + 16 * half);
+      }
+    }
+  }
+  drain();
+  SFM_STAMP_END(t1 - t0);
+  int se[2], sh[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    se[k] = ce[k] + __shfl_xor(ce[k], 32);
+    sh[k] = ch[k] + __shfl_xor(ch[k], 32);
+  }
+  const unsigned ok = fin[wave][lane];
+  const int oute = (ok & 1u) ? (half ? se[1] : se[0]) + (kDoE ? qcnt[wave][0][lane] : 0) : 0;
+  const int outh = (ok & 2u) ? (half ? sh[1] : sh[0]) + (kDoH ? qcnt[wave][(kDoE && kDoH) ? 1 : 0][lane] : 0) : 0;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // the hypothesis id is formed again here rather than held in two registers across the tile loop
   const long long out_id = (long long)blockIdx.x * blockDim.x + tid;
   if (out_id < nb) {
     if (use_atomics) {
@@ -1791,6 +2200,7 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
         closest = min3_abs(closest, d0, d1);
       }
       cnt[k] += __popc(hneg & vmask);
+      SFM_STAMP_COUNT(closest <= band[k]);
       if (closest <= band[k]) {  // rare: some pair of this row is too close to the threshold for its float32 sign (or is padding)
         unsigned hamb = 0;
 #pragma unroll
@@ -2141,6 +2551,16 @@ inline int choose_splits(long long tiles, int npoints) {
   return (int)s;
 }
 
+// workgroups of `kernel` that the current device holds at once (0 when the query fails)
+template <typename K>
+long long chip_slots(K kernel) {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess) return 0;
+  return (long long)cus * per_cu;
+}
+
 }  // namespace
 
 #define SFM_TRY(expr)            \
@@ -2352,9 +2772,12 @@ int sfm_eh_upper_mfma_part_f32(const double* corr, const void* corrm, int32_t n,
   return launch_eh_upper_mfma(corr, corrm, n, idx, nb, thr_e, thr_h, xmax, safety, up_e, up_h, (hipStream_t)stream, part);
 }
 
+// bytes of match-side operands per match: six 32-byte piece vectors + (x2, y2) as float32
+constexpr int kEhxBytesPerMatch = kEhxVecA * 32 + 8;
+
 int64_t sfm_eh_score_mixed_workspace_bytes(int64_t nb, int32_t n) {
   if (nb < 0 || n <= 0) return -1;
-  return ((int64_t)padded32(n) * 72 + 16 + 255) / 256 * 256;
+  return ((int64_t)padded32(n) * kEhxBytesPerMatch + 16 + 255) / 256 * 256;
 }
 
 // workspace: sfm_eh_score_mixed_workspace_bytes(nb, n) bytes of device memory, 256-byte aligned (checked by the callers)
@@ -2369,10 +2792,16 @@ static int run_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx,
   if (tiles > 0x7FFFFFFFLL) return SFM_EINVAL;
   const int npad = padded32(n);
   const int ntiles = npad / 32;
+  // SFM_HIP_EHX_FORM=0: the epipolar test from the rows E x1 and E^T x2 on the vector ALU (eh_score_mfma_kernel, 72 bytes of
+  // operands per match) instead of s, n1, n2 whole from the matrix cores (eh_score_mfma2_kernel, 200 bytes per match)
+  static const bool form2_env = !(getenv("SFM_HIP_EHX_FORM") && atoi(getenv("SFM_HIP_EHX_FORM")) == 0);
+  const bool form2 = form2_env && n < (1 << 25);  // its queue entries keep the match index in 25 bits
   uint4* pieces = (uint4*)workspace;
-  float2* xy = (float2*)((char*)workspace + (size_t)npad * 64);
+  float2* xy = (float2*)((char*)workspace + (size_t)npad * (form2 ? kEhxVecA * 32 : 64));
   int splits = choose_splits(tiles, n);
-  static const int span = getenv("SFM_HIP_EHX_SPAN") ? atoi(getenv("SFM_HIP_EHX_SPAN")) : 32768;  // as in launch_eh_upper_mfma (72 bytes per match here)
+  // the span of matches that the workgroups in flight share in L2 (as in launch_eh_upper_mfma)
+  static const int span_env = getenv("SFM_HIP_EHX_SPAN") ? atoi(getenv("SFM_HIP_EHX_SPAN")) : -1;
+  const int span = span_env >= 0 ? span_env : (form2 ? 12288 : 32768);
   if (span > 0 && tiles > 1 && splits < div_up(n, span)) splits = div_up(n, span);
   if (splits > ntiles) splits = ntiles;
   const int tps = div_up(ntiles, splits);
@@ -2381,17 +2810,65 @@ static int run_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx,
     SFM_TRY(hipMemsetAsync(count_h, 0, sizeof(int32_t) * nb, st));
   }
   SFM_TRY(hipMemsetAsync(xy + npad, 0, 16, st));  // trailer: measured max |coordinate|
-  corr_to_mfma2_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, pieces, xy);
+  if (form2)
+    corr_to_mfma3_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, pieces, xy);
+  else
+    corr_to_mfma2_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, pieces, xy);
   SFM_TRY(check_launch());
   // two launches (one model each, at a higher occupancy) pay from about 2^28 pairs on; below that the second launch costs more
   static const int split_env = getenv("SFM_HIP_EHX_SPLIT") ? atoi(getenv("SFM_HIP_EHX_SPLIT")) : -1;
   const bool split_models = split_env >= 0 ? split_env != 0 : (long long)nb * n >= (1LL << 28);
   const dim3 grid((unsigned)tiles, splits);
+  // SFM_HIP_EHX_PART=1 / 2: a timing aid, only the E / only the H launch of the two-launch form (the other count array is not written)
+  static const int part = getenv("SFM_HIP_EHX_PART") ? atoi(getenv("SFM_HIP_EHX_PART")) : 0;
+  if (form2) {
+    if (split_models) {
+      // As in launch_eh_upper_mfma: a last round of the grid that is less than a quarter full is launched apart with its
+      // match range cut into pieces (the E launch holds 768 workgroups at a time: 3907 of them are 5.09 rounds).
+      static const bool cut_tail = !(getenv("SFM_HIP_EHX_TAIL") && atoi(getenv("SFM_HIP_EHX_TAIL")) == 0);
+      static const long long slots_e = chip_slots(eh_score_mfma2_kernel<true, false, 3>), slots_h = chip_slots(eh_score_mfma2_kernel<false, true, 4>);
+      auto launch_model = [&](bool model_e, long long slots) -> int {
+        auto one = [&](long long t_lo, long long t_hi, int sp, bool zeroed) -> int {
+          const long long off = t_lo * kBlock;
+          const long long cnt = (t_hi * kBlock < nb ? t_hi * kBlock : nb) - off;
+          int32_t* dst = (model_e ? count_e : count_h) + off;
+          if (sp > 1 && !zeroed) SFM_TRY(hipMemsetAsync(dst, 0, sizeof(int32_t) * cnt, st));
+          const dim3 g((unsigned)(t_hi - t_lo), sp);
+          const int tp = div_up(ntiles, sp);
+          if (model_e)
+            eh_score_mfma2_kernel<true, false, 3><<<g, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, 2.0 * thr_e * thr_e,
+                                                                       thr_h * thr_h, xmax, count_e + off, count_h + off, tp, sp > 1);
+          else
+            eh_score_mfma2_kernel<false, true, 4><<<g, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, 2.0 * thr_e * thr_e,
+                                                                       thr_h * thr_h, xmax, count_e + off, count_h + off, tp, sp > 1);
+          return check_launch();
+        };
+        const long long rem = slots > 0 ? tiles % slots : 0;
+        if (cut_tail && splits == 1 && tiles > slots && rem > 0 && rem * 4 <= slots) {
+          int sp = (int)(slots / rem);
+          if (sp > 16) sp = 16;  // every piece solves its hypotheses again: keep that below the work it saves
+          if (sp > ntiles) sp = ntiles;
+          SFM_TRY(one(0, tiles - rem, 1, false));
+          return one(tiles - rem, tiles, sp, false);
+        }
+        return one(0, tiles, splits, true);  // with splits > 1 both count arrays were zeroed above
+      };
+      if (part != 2) SFM_TRY(launch_model(true, slots_e));
+      if (part != 1) SFM_TRY(launch_model(false, slots_h));
+      return 0;
+    } else {
+      eh_score_mfma2_kernel<true, true, 2><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e,
+                                                                   thr_h * thr_h, xmax, count_e, count_h, tps, splits > 1);
+    }
+    return check_launch();
+  }
   if (split_models) {
-    eh_score_mfma_kernel<true, false, 3><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e, thr_h * thr_h,
-                                                                 xmax, count_e, count_h, tps, splits > 1);
+    if (part != 2)
+      eh_score_mfma_kernel<true, false, 3><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e, thr_h * thr_h,
+                                                                   xmax, count_e, count_h, tps, splits > 1);
     SFM_TRY(check_launch());
-    eh_score_mfma_kernel<false, true, 4><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e, thr_h * thr_h,
+    if (part != 1)
+      eh_score_mfma_kernel<false, true, 4><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e, thr_h * thr_h,
                                                                  xmax, count_e, count_h, tps, splits > 1);
   } else {
     eh_score_mfma_kernel<true, true, 2><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e, thr_h * thr_h,
@@ -2412,7 +2889,7 @@ int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_
 // The match-side operands live in a file-scope device array instead of a caller workspace.  Each GPU holds its own
 // copy of the array at its own address: the address is looked up once per device (with that device current) and kept;
 // host code only ever uses that looked-up pointer, never the array's name.
-static constexpr size_t kNoallocBytes = ((size_t)SFM_NOALLOC_MAX_MATCHES * 72 + 16 + 255) / 256 * 256;
+static constexpr size_t kNoallocBytes = ((size_t)SFM_NOALLOC_MAX_MATCHES * kEhxBytesPerMatch + 16 + 255) / 256 * 256;
 static __device__ __align__(256) unsigned char scratch[kNoallocBytes];
 namespace {
 constexpr int kMaxDevices = 64;
