@@ -76,15 +76,11 @@ def load_traffic():
         return json.load(f), os.path.relpath(files[-1], ROOT)
 
 
-def traffic_of(table, prefix, grid=None):
-    """Memory-side bytes per launch of the kernels whose name starts with prefix (at the given grid size, else the largest
-    profiled): (sum over the instantiations, {name: bytes})."""
+def traffic_of(table, prefix):
+    """Memory-side bytes per CALL of the kernels whose name starts with prefix: the probe makes each call on one shape only,
+    so every (instantiation, grid) row of that name is one launch of the call (the exact scorer launches one model at a
+    time and the nearly empty last round of a grid apart): (sum over the rows, {row: bytes})."""
     rows = {k: v["bytes_per_launch"] for k, v in table.items() if k.startswith(prefix)}
-    if grid is not None:
-        rows = {k: v for k, v in rows.items() if k.endswith(f"grid {grid}")}
-    elif rows:
-        top = max(int(k.rsplit(" ", 1)[1]) for k in rows)
-        rows = {k: v for k, v in rows.items() if k.endswith(f"grid {top}")}
     return (sum(rows.values()), rows) if rows else (None, None)
 
 
@@ -1130,28 +1126,30 @@ def main():
         table, counters_file = load_profile_counters(n, B)
         traffic_table, traffic_file = load_traffic()
         default_shape = (n, B) == (10000, 1000000)
-        traffic, traffic_parts = traffic_of(traffic_table, "eh_score_mfma_kernel", (B + 255) // 256 * 256) if default_shape else (None, None)
+        traffic, traffic_parts = traffic_of(traffic_table, "eh_score_mfma2_kernel") if default_shape else (None, None)
         bound_issue = issue_roofline(kern_ms, kernel_counters(table, "eh_upper_mfma_kernel<true, true", per_call=True))
-        exact_issue = issue_roofline(mixed_ms, kernel_counters_sum(table, "eh_score_mfma_kernel", mixed_ms)
-                                     or kernel_counters(table, "eh_score_mfma_kernel", kernel_ms=mixed_ms))
+        exact_issue = issue_roofline(mixed_ms, kernel_counters_sum(table, "eh_score_mfma2_kernel", mixed_ms)
+                                     or kernel_counters(table, "eh_score_mfma2_kernel", kernel_ms=mixed_ms))
         if bound_issue is not None and default_shape:
-            bound_issue["memory_bytes_per_launch"] = traffic_of(traffic_table, "eh_upper_mfma_kernel<true, true, true>")[0]
+            bound_issue["memory_bytes_per_call"] = traffic_of(traffic_table, "eh_upper_mfma_kernel<true, true, true>")[0]
         achieved = flops_per_launch / (mixed_ms * 1e-3) / 1e12
         roofline = {
             "bound": "valu_fp32",
-            "kernel": "eh_score_mfma_kernel (one launch per model from 2^28 pairs on: <true, false, 3> for E and <false, true, 4> for H; rows "
-            "E x1, E^T x2 and H x1 on the bf16 matrix cores from three-piece splits, the reference's symmetric epipolar and transfer tests in "
-            "float32 for every pair, float64 inside the rigorous error band; float64 model solve included)",
+            "kernel": "eh_score_mfma2_kernel (one launch per model: <true, false, 3> for E and <false, true, 4> for H; the bilinear form "
+            "s = x2^T E x1, the squared line norms and the row H x1 on the bf16 matrix cores from three-piece splits, the reference's symmetric "
+            "epipolar and transfer tests in float32 for every pair, float64 for the pairs inside the rigorous error band; float64 model solve "
+            "included)",
             "achieved": achieved,
             "peak": PEAK_FP32_VALU_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_VALU_TFLOPS,
             "frac_from_value": value / world * (FLOPS_PER_E_EVAL + FLOPS_PER_H_EVAL) / 2.0 / 1e12 / PEAK_FP32_VALU_TFLOPS,
             "traffic": traffic,
-            "traffic_unit": "bytes per call (both launches): FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes over "
-            "profiles/tools/traffic_probe.py (this library call on this shape, one launch at a time; the file named in traffic_from).  Each of "
-            "the two launches reads the 48 MB of index rows (whole 128-byte lines are fetched although a model uses 32 or 16 of a row's 48 "
-            "bytes) and the 1 MB of matches once per XCD (8 L2s); 8 MB of counts are written",
+            "traffic_unit": "bytes per call (all its launches): FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes over "
+            "profiles/tools/traffic_probe.py (this library call on this shape, one launch at a time; the file named in traffic_from).  Each "
+            "model's launch reads the 48 MB of index rows (whole 128-byte lines are fetched although a model uses 32 or 16 of a row's 48 "
+            "bytes) and the 2 MB of match operands once per XCD (8 L2s); 8 MB of counts are written; the last, nearly empty round of the E "
+            "grid is launched apart in 11 pieces (its 67 tiles read their index rows 11 times)",
             "traffic_per_launch": traffic_parts,
             "traffic_from": traffic_file,
             "counters_from": counters_file,

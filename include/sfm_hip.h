@@ -108,8 +108,9 @@ int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_
                 void* stream);
 
 /* sfm_eh_score_f64 with the bulk of the residual tests on the bf16 matrix cores + float32 and IDENTICAL counts: the
- * rows E x1, E^T x2 and H x1 come from MFMAs of three-piece splits; a pair whose float32 test value lies inside the
- * rigorous error band around the threshold is re-evaluated with the float64 test inside the kernel.
+ * bilinear form s = x2^T E x1, the squared line norms |(E x1)_{0,1}|^2, |(E^T x2)_{0,1}|^2 and the row H x1 come from MFMAs
+ * of three-piece splits; a pair whose float32 test value lies inside the rigorous error band around the threshold is
+ * re-evaluated with the float64 test inside the kernel (queued per wave, 64 pairs at a time).
  * xmax: hint, see Conventions.  workspace: sfm_eh_score_mixed_workspace_bytes(nb, n) bytes, 256-byte aligned. */
 int64_t sfm_eh_score_mixed_workspace_bytes(int64_t nb, int32_t n);
 int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax,
@@ -117,8 +118,8 @@ int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_
 
 /* sfm_eh_score_mixed for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc): same counts, no workspace argument, and no hipMalloc / hipFree or other
- * allocating call inside.  It has no counterpart in the reference.  The match-side operands (72 bytes per match) go into
- * a fixed array inside the library, SFM_NOALLOC_MAX_MATCHES * 72 bytes (2.25 MiB) that every GPU the library runs on
+ * allocating call inside.  It has no counterpart in the reference.  The match-side operands (200 bytes per match) go into
+ * a fixed array inside the library, SFM_NOALLOC_MAX_MATCHES * 200 bytes (6.25 MiB) that every GPU the library runs on
  * holds until the process ends; n beyond that capacity is rejected with SFM_ETOOLARGE.  All calls on one GPU share
  * that array: calls that overlap on one GPU (different streams or threads) race; calls on one stream are safe.
  * The array used is the one of the GPU that owns `stream` (of the current GPU for a NULL stream); the kernels are

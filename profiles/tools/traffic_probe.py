@@ -65,7 +65,7 @@ def collect(fetch_dir, write_dir, out):
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 name = r["Kernel_Name"]
-                if r["Counter_Name"] != key or "mfma_kernel" not in name or "corr_to" in name or "t_prep" in name:
+                if r["Counter_Name"] != key or "mfma" not in name or "_kernel" not in name or "corr_to" in name or "t_prep" in name:
                     continue
                 short = re.search(r"(\w+_kernel(<[^>]*>)?)", name).group(1)
                 table.setdefault(f"{short} grid {r['Grid_Size']}", {}).setdefault(key, []).append(float(r["Counter_Value"]))

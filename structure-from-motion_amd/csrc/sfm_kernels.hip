@@ -1383,11 +1383,14 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     se[k] = ce[k] + __shfl_xor(ce[k], 32);
     sh[k] = ch[k] + __shfl_xor(ch[k], 32);
   }
-  const unsigned ok = fin[wave][lane];
-  const int oute = (ok & 1u) ? (half ? se[1] : se[0]) + (kDoE ? qcnt[wave][0][lane] : 0) : 0;
-  const int outh = (ok & 2u) ? (half ? sh[1] : sh[0]) + (kDoH ? qcnt[wave][(kDoE && kDoH) ? 1 : 0][lane] : 0) : 0;
+  // thread ids are formed again here: values derived from them and held across the tile loop only for these last lines cost
+  // registers there (a spill at three waves per SIMD)
   int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));  // the hypothesis id is formed again here rather than held in two registers across the tile loop
+  asm volatile("" : "+v"(tid));
+  const int lane_o = tid & 63, wave_o = tid >> 6, half_o = lane_o >> 5;
+  const unsigned ok = fin[wave_o][lane_o];
+  const int oute = (ok & 1u) ? (half_o ? se[1] : se[0]) + (kDoE ? qcnt[wave_o][0][lane_o] : 0) : 0;
+  const int outh = (ok & 2u) ? (half_o ? sh[1] : sh[0]) + (kDoH ? qcnt[wave_o][(kDoE && kDoH) ? 1 : 0][lane_o] : 0) : 0;
   const long long out_id = (long long)blockIdx.x * blockDim.x + tid;
   if (out_id < nb) {
     if (use_atomics) {
@@ -2108,8 +2111,11 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
                                                                  const int32_t* __restrict__ idx, long long nb, double thr2,
                                                                  int* __restrict__ counts, int tiles_per_split, int use_atomics,
                                                                  int grid_tiles, int grid_cams, int grid_splits) {
+  constexpr int kQueue = 256;  // pairs whose float32 sign is not trusted wait here for a dense float64 pass (per wave)
   __shared__ uint4 bstage[kBlock / 64][64][3][2];
   __shared__ double tstage[kBlock / 64][64][3];
+  __shared__ unsigned qbuf[kBlock / 64][kQueue];
+  __shared__ int qcnt[kBlock / 64][64];
   SFM_STAMP_ENTRY();
   __builtin_amdgcn_s_setprio(3);  // the solve runs ahead of the other waves' tile loops (see eh_upper_mfma_kernel)
   // grid_tiles == 0: a 3-D grid (hypothesis tile, camera, split).  Otherwise a 1-D grid of grid_tiles * grid_cams *
@@ -2179,6 +2185,39 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
   const f32x16 zero = {0};
   const unsigned tail_mask = tile_tail_mask(m, half);
   const uint4* src = pc + 6 * (t0 * 32 + apos) + half;
+  // Pairs inside a band are not evaluated where they are found (a lane or two at a time with the rest of the wave idle, on a
+  // quarter of all rows): their (correspondence, hypothesis) ids are appended to a queue of the wave, which is worked off 64
+  // pairs at a time with the float64 test of t_score_kernel; the verdicts are added to per-hypothesis counters in LDS.
+  qcnt[wave][lane] = 0;
+  int qlen = 0;
+  auto drain = [&]() {
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < qlen; base += 64) {
+      if (base + lane < qlen) {
+        const unsigned e = qbuf[wave][base + lane];
+        const int h = (int)(e & 63u);
+        const double* T = tstage[wave][h];
+        const double* p = pts + 6LL * (e >> 6);
+        if (reprojection_inlier<double>(T[0], T[1], T[2], p[0], p[1], p[2], p[3], p[4], thr2)) atomicAdd(&qcnt[wave][h], 1);
+      }
+    }
+    qlen = 0;
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto enqueue = [&](unsigned amb, int hyp_of_wave, int first) {  // called by the whole wave; bit 15-i of amb = correspondence first + i
+    unsigned long long any = __ballot(amb != 0u);
+    while (any) {
+      const bool act = amb != 0u;
+      const int bit = __ffs((int)amb) - 1;
+      amb &= amb - 1u;
+      const unsigned entry = ((unsigned)(first + 15 - bit) << 6) | (unsigned)hyp_of_wave;
+      const int pos = qlen + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(any >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)any, 0u));
+      if (act) qbuf[wave][pos] = entry;
+      qlen += __popcll(any);
+      if (qlen > kQueue - 64) drain();
+      any = __ballot(amb != 0u);
+    }
+  };
   __builtin_amdgcn_s_setprio(0);
   SFM_STAMP_BEGIN();
   for (int t = t0; t < t1; ++t, src += 192) {
@@ -2201,29 +2240,23 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
       }
       cnt[k] += __popc(hneg & vmask);
       SFM_STAMP_COUNT(closest <= band[k]);
-      if (closest <= band[k]) {  // rare: some pair of this row is too close to the threshold for its float32 sign (or is padding)
+      if (__ballot(closest <= band[k])) {  // rare per row, not per wave: some pair of some lane's row is too close to the threshold (or is padding)
         unsigned hamb = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float d = fma(-q[i], q[i], fma(dy[i], dy[i], dx[i] * dx[i]));  // the same instructions give the same value again
           hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(d) - band[k]), 31);  // <= 0 would be exact; < 0 after the inflation of band
         }
-        unsigned amb = band[k] == __builtin_inff() ? vmask : (hamb & vmask);  // an unusable hypothesis takes the float64 test everywhere
+        const unsigned amb = band[k] == __builtin_inff() ? vmask : (hamb & vmask);  // an unusable hypothesis takes the float64 test everywhere
         cnt[k] -= __popc(hneg & amb);  // take the untrusted signs back out
-        const double* T = tstage[wave][32 * k + col];
-        const double T0 = T[0], T1 = T[1], T2 = T[2];
-        while (amb) {
-          const int b = __ffs((int)amb) - 1;  // bit 15-i of a history is correspondence 16*half + i of the tile
-          amb &= amb - 1;
-          const double* p = pts + 6LL * (t * 32 + 16 * half + 15 - b);
-          cnt[k] += reprojection_inlier<double>(T0, T1, T2, p[0], p[1], p[2], p[3], p[4], thr2) ? 1 : 0;
-        }
+        enqueue(amb, 32 * k + col, t * 32 + 16 * half);
       }
     }
   }
+  drain();
   SFM_STAMP_END(t1 - t0);
   const int s0 = cnt[0] + __shfl_xor(cnt[0], 32), s1 = cnt[1] + __shfl_xor(cnt[1], 32);
-  const int out = half ? s1 : s0;  // lane L reports hypothesis L = 32*half + col
+  const int out = (half ? s1 : s0) + qcnt[wave][lane];  // lane L reports hypothesis L = 32*half + col
   if (gid < nb) {
     int* dst = counts + (long long)cam * nb + gid;
     if (use_atomics)
@@ -2822,45 +2855,40 @@ static int run_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx,
   // SFM_HIP_EHX_PART=1 / 2: a timing aid, only the E / only the H launch of the two-launch form (the other count array is not written)
   static const int part = getenv("SFM_HIP_EHX_PART") ? atoi(getenv("SFM_HIP_EHX_PART")) : 0;
   if (form2) {
-    if (split_models) {
-      // As in launch_eh_upper_mfma: a last round of the grid that is less than a quarter full is launched apart with its
-      // match range cut into pieces (the E launch holds 768 workgroups at a time: 3907 of them are 5.09 rounds).
-      static const bool cut_tail = !(getenv("SFM_HIP_EHX_TAIL") && atoi(getenv("SFM_HIP_EHX_TAIL")) == 0);
-      static const long long slots_e = chip_slots(eh_score_mfma2_kernel<true, false, 3>), slots_h = chip_slots(eh_score_mfma2_kernel<false, true, 4>);
-      auto launch_model = [&](bool model_e, long long slots) -> int {
-        auto one = [&](long long t_lo, long long t_hi, int sp, bool zeroed) -> int {
-          const long long off = t_lo * kBlock;
-          const long long cnt = (t_hi * kBlock < nb ? t_hi * kBlock : nb) - off;
-          int32_t* dst = (model_e ? count_e : count_h) + off;
-          if (sp > 1 && !zeroed) SFM_TRY(hipMemsetAsync(dst, 0, sizeof(int32_t) * cnt, st));
-          const dim3 g((unsigned)(t_hi - t_lo), sp);
-          const int tp = div_up(ntiles, sp);
-          if (model_e)
-            eh_score_mfma2_kernel<true, false, 3><<<g, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, 2.0 * thr_e * thr_e,
-                                                                       thr_h * thr_h, xmax, count_e + off, count_h + off, tp, sp > 1);
-          else
-            eh_score_mfma2_kernel<false, true, 4><<<g, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, 2.0 * thr_e * thr_e,
-                                                                       thr_h * thr_h, xmax, count_e + off, count_h + off, tp, sp > 1);
-          return check_launch();
-        };
-        const long long rem = slots > 0 ? tiles % slots : 0;
-        if (cut_tail && splits == 1 && tiles > slots && rem > 0 && rem * 4 <= slots) {
-          int sp = (int)(slots / rem);
-          if (sp > 16) sp = 16;  // every piece solves its hypotheses again: keep that below the work it saves
-          if (sp > ntiles) sp = ntiles;
-          SFM_TRY(one(0, tiles - rem, 1, false));
-          return one(tiles - rem, tiles, sp, false);
-        }
-        return one(0, tiles, splits, true);  // with splits > 1 both count arrays were zeroed above
+    // always one launch per model (at 3 and 4 waves per SIMD; a fused instantiation would need 256 registers and spill)
+    // As in launch_eh_upper_mfma: a last round of the grid that is less than a quarter full is launched apart with its
+    // match range cut into pieces (the E launch holds 768 workgroups at a time: 3907 of them are 5.09 rounds).
+    static const bool cut_tail = !(getenv("SFM_HIP_EHX_TAIL") && atoi(getenv("SFM_HIP_EHX_TAIL")) == 0);
+    static const long long slots_e = chip_slots(eh_score_mfma2_kernel<true, false, 3>), slots_h = chip_slots(eh_score_mfma2_kernel<false, true, 4>);
+    auto launch_model = [&](bool model_e, long long slots) -> int {
+      auto one = [&](long long t_lo, long long t_hi, int sp, bool zeroed) -> int {
+        const long long off = t_lo * kBlock;
+        const long long cnt = (t_hi * kBlock < nb ? t_hi * kBlock : nb) - off;
+        int32_t* dst = (model_e ? count_e : count_h) + off;
+        if (sp > 1 && !zeroed) SFM_TRY(hipMemsetAsync(dst, 0, sizeof(int32_t) * cnt, st));
+        const dim3 g((unsigned)(t_hi - t_lo), sp);
+        const int tp = div_up(ntiles, sp);
+        if (model_e)
+          eh_score_mfma2_kernel<true, false, 3><<<g, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, 2.0 * thr_e * thr_e,
+                                                                     thr_h * thr_h, xmax, count_e + off, count_h + off, tp, sp > 1);
+        else
+          eh_score_mfma2_kernel<false, true, 4><<<g, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, 2.0 * thr_e * thr_e,
+                                                                     thr_h * thr_h, xmax, count_e + off, count_h + off, tp, sp > 1);
+        return check_launch();
       };
-      if (part != 2) SFM_TRY(launch_model(true, slots_e));
-      if (part != 1) SFM_TRY(launch_model(false, slots_h));
-      return 0;
-    } else {
-      eh_score_mfma2_kernel<true, true, 2><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx, nb, 2.0 * thr_e * thr_e,
-                                                                   thr_h * thr_h, xmax, count_e, count_h, tps, splits > 1);
-    }
-    return check_launch();
+      const long long rem = slots > 0 ? tiles % slots : 0;
+      if (cut_tail && splits == 1 && tiles > slots && rem > 0 && rem * 4 <= slots) {
+        int sp = (int)(slots / rem);
+        if (sp > 16) sp = 16;  // every piece solves its hypotheses again: keep that below the work it saves
+        if (sp > ntiles) sp = ntiles;
+        SFM_TRY(one(0, tiles - rem, 1, false));
+        return one(tiles - rem, tiles, sp, false);
+      }
+      return one(0, tiles, splits, true);  // with splits > 1 both count arrays were zeroed above
+    };
+    if (part != 2) SFM_TRY(launch_model(true, slots_e));
+    if (part != 1) SFM_TRY(launch_model(false, slots_h));
+    return 0;
   }
   if (split_models) {
     if (part != 2)
