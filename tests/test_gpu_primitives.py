@@ -1,5 +1,7 @@
 """GPU parity of every C-ABI entry point against the oracle and the golden fixtures.
 Run on the MI355X box with -m gpu; all calls go through libsfm_hip.so."""
+import os
+
 import numpy as np
 import pytest
 
@@ -492,6 +494,72 @@ def test_mixed_eh_scoring_on_the_threshold_and_degenerate_inputs(ops, dev):
     a = ops.eh_score(same, idx2, 4e-4, 1.2e-3)
     b = ops.eh_score_mixed(same, idx2, 4e-4, 1.2e-3, 0.2)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_mixed_eh_scoring_in_other_coordinate_scales_and_near_the_epipoles(ops, dev):
+    """The exact scorer takes s = x2^T E x1 and the squared line norms whole from the matrix cores and decides
+    s^2 (n1 + n2) < k n1 n2 with a band derived from the coordinate bound: the counts must equal the float64 kernel's for
+    pixel coordinates (|x| up to 2000, thresholds in pixels), for tiny coordinates, for matches piled up around both
+    epipoles (vanishing line norms), for thresholds from 0.01 to 30 px, and with a few wild coordinates in the set."""
+    import torch
+
+    sc, x1, x2 = scene(n=3000, inl=0.5, pl=0.3, seed=21)
+    K = np.asarray(sc["K"], np.float64)
+    B = 6000
+    rng = np.random.default_rng(5)
+    cases = []
+    for name, scale, thr_px in (("pixels", K[0, 0], 1.0), ("pixels, tight", K[0, 0], 0.01), ("pixels, loose", K[0, 0], 30.0),
+                                ("normalised", 1.0, 1.0), ("tiny", 1e-4, 1.0), ("large", 6.0, 2.0)):
+        c = ops.pack_corr(x1, x2) * scale
+        cases.append((name, c, thr_px * scale / K[0, 0]))
+    # matches around the epipoles of the true geometry: E e1 = 0, E^T e2 = 0
+    F = orc.estimate_F_DLT(x1[:, sc["is_inlier"]][:, :200], x2[:, sc["is_inlier"]][:, :200])
+    E = orc.enforce_essential(F)
+    u, sv, vt = np.linalg.svd(E)
+    e1, e2 = vt[2] / vt[2, 2], u[:, 2] / u[2, 2]
+    c = ops.pack_corr(x1, x2).copy()
+    if np.all(np.isfinite(e1)) and np.all(np.isfinite(e2)) and max(np.abs(e1).max(), np.abs(e2).max()) < 50:
+        c[:600, 0:2] = e1[:2] + rng.normal(0, 1e-4, (600, 2))
+        c[300:900, 2:4] = e2[:2] + rng.normal(0, 1e-4, (600, 2))
+    cases.append(("epipoles", c, 1.0 / K[0, 0]))
+    c = ops.pack_corr(x1, x2).copy()
+    c[::97] *= 300.0  # a few wild matches raise the coordinate bound of the whole set
+    cases.append(("wild", c, 1.0 / K[0, 0]))
+    for name, c, thr in cases:
+        corr = dev(np.ascontiguousarray(c))
+        idx_h = rng.integers(0, c.shape[0], size=(B, 12)).astype(np.int32)
+        inl = np.flatnonzero(sc["is_inlier"])
+        idx_h[:1500] = inl[rng.integers(0, len(inl), size=(1500, 12))]  # many good models: dense around the threshold
+        idx = dev(idx_h)
+        ce, ch = ops.eh_score(corr, idx, thr, 3 * thr)
+        me, mh = ops.eh_score_mixed(corr, idx, thr, 3 * thr)
+        assert torch.equal(ce, me), (name, int((ce != me).sum()), int((ce - me).abs().max()))
+        assert torch.equal(ch, mh), (name, int((ch != mh).sum()))
+        assert int(ce.max()) > 0
+
+
+def test_previous_form_of_the_exact_scorer_still_agrees(ops, dev):
+    """SFM_HIP_EHX_FORM=0 keeps the round-2 form of the exact scorer reachable (it is read once per process: child process)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, os, numpy as np, torch\n"
+        "sys.path.insert(0, os.path.join(os.getcwd(), 'structure-from-motion_amd'))\n"
+        "from sfm_hip import _capi, ops, synthetic\n"
+        "_capi.load_library()\n"
+        "sc = synthetic.two_view_scene(n=2500, inlier_ratio=0.4, planar_ratio=0.5, seed=4)\n"
+        "Kinv = np.linalg.inv(np.asarray(sc['K'], float))\n"
+        "x1 = Kinv @ np.vstack((sc['x1'][:2], np.ones((1, 2500)))); x2 = Kinv @ np.vstack((sc['x2'][:2], np.ones((1, 2500))))\n"
+        "corr = _capi.dev(ops.pack_corr(x1, x2)); idx = ops.index_sets(1, 0, 120000, 2500); thr = 1.0 / sc['K'][0][0]\n"
+        "a = ops.eh_score(corr, idx, thr, 3 * thr); b = ops.eh_score_mixed(corr, idx, thr, 3 * thr)\n"
+        "assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])\n"
+        "print('same')\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SFM_HIP_EHX_FORM="0")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0 and "same" in out.stdout, out.stderr[-2000:]
 
 
 def test_matrix_core_bounds_with_operands_of_another_threshold_stay_valid(ops, dev):
