@@ -855,8 +855,8 @@ def run_c5(args, torch, dist, orc, _capi, ops, sharding, synthetic, world, rank,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 60 for c2, 6 for c5, whose steps take seconds)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default: 15 for c2, 2 for c5)")
     ap.add_argument("--workload", choices=["auto", "c2", "c5"], default="auto",
                     help="c2: 10 000 matches x 10^6 hypotheses per GPU (weak scaling); c5: 200 000 matches x 10^8 hypotheses in total, split over "
                     "the GPUs (strong scaling); auto = c2 on one GPU, c5 on several")
@@ -888,6 +888,10 @@ def main():
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     workload = args.workload if args.workload != "auto" else ("c2" if world_env == 1 else "c5")
+    if args.steps is None:
+        args.steps = 60 if workload == "c2" else 6
+    if args.warmup is None:
+        args.warmup = 15 if workload == "c2" else 2
     all_cores = None
     side_runs = args.e2e or args.sweep or args.e2e_images or args.sift_vs_oracle
     if args.cpu_all_cores < 0:
