@@ -7,7 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "structure-from-motion_amd"))
 import numpy as np  # noqa: E402
 
-from sfm_hip import _capi, ops, synthetic  # noqa: E402
+from sfm_hip import _capi  # noqa: E402
+
+if os.environ.get("SFM_DIAG_LIB"):  # an experimental build of the library
+    _capi.LIB_PATH = os.environ["SFM_DIAG_LIB"]
+from sfm_hip import ops, synthetic  # noqa: E402
 
 
 def main():
