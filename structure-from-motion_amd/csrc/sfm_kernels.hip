@@ -375,8 +375,9 @@ __global__ __launch_bounds__(kBlock) void eh_upper_kernel(const double4* __restr
 // Measured alternatives (same results, slower): hypotheses as rows with scalar popcounts of the
 // compare masks (the one scalar ALU per CU becomes the bottleneck: 4.6 ms against 3.5 ms on the
 // 10^4 x 10^6 workload) and a software pipeline that issues the next stage's MFMAs before the
-// current stage's vector work (4.0 ms at 251 VGPRs).  The kernel runs at about 1.8 GHz, i.e. on
-// the power limit: what counts is the number of instructions, matrix-core ones included.
+// current stage's vector work (4.0 ms at 251 VGPRs).  In-kernel clock stamps show 1.95-2.0 GHz
+// under this kernel; what counts is the number of ISSUE SLOTS: v_alignbit, v_min3, v_cmp issue at
+// half rate on gfx950, which is why the default form below counts with clamped floats instead.
 //
 // Error bound used for the slack (upper-bound property): piece expansion (dropped products and
 // residuals) <= 2^-24 R, accumulation inside the matrix core <= 32 * 2^-24 R for any summation
@@ -716,7 +717,8 @@ __global__ __launch_bounds__(kBlock, 3) void eh_upper_mfma_kernel(const double4*
 }
 
 // ---------------------------------------------------------------------------------------
-// EXACT E/H counts (those of eh_score_kernel) at matrix-core + float32 cost: the scheme of
+// EXACT E/H counts (those of eh_score_kernel) at matrix-core + float32 cost, FIRST FORM (launched only with
+// SFM_HIP_EHX_FORM=0 or for more than 2^25 matches; eh_score_mfma2_kernel below is the form in use): the scheme of
 // t_score_mfma_kernel applied to both tests.  Rows l = E x1, (m0, m1) = (E^T x2)_{0,1} and h = H x1 come
 // from bf16 MFMAs of three-piece splits; the float32 values
 //     fE = |s| - sqrt(k) g,  g = sqrt(n1 n2 / (n1 + n2))        and        dH = dx^2 + dy^2 - (sqrt(T) hz)^2
