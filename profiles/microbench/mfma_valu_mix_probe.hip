@@ -111,6 +111,86 @@ __global__ __launch_bounds__(1024) void kchain(Rec* out, const uint4* __restrict
   if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = Rec{iters, t1 - t0, r1 - r0};
 }
 
+// The chained shape software-pipelined inside a wave: the MFMAs of iteration i + 1 are issued before the vector
+// instructions of iteration i, into a second set of accumulators (48 more registers: two waves per SIMD at most).
+template <int C0, int C1, int C2, int N, int LB>
+__global__ __launch_bounds__(LB) void kchain_pipelined(Rec* out, const uint4* __restrict__ in, unsigned long long ticks) {
+  const uint4 ua = in[threadIdx.x & 255], ub = in[256 + (threadIdx.x & 255)];
+  bf16x8 a[3][4], b[3][4];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      a[c][m] = __builtin_bit_cast(bf16x8, ua);
+      b[c][m] = __builtin_bit_cast(bf16x8, ub);
+      asm volatile("" : "+v"(a[c][m]), "+v"(b[c][m]));
+    }
+  float x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = __uint_as_float(ua.x) * (i + 1);
+  const float c0 = __uint_as_float(ub.y);
+  const f32x16 zero = {0};
+  f32x16 cur[3] = {zero, zero, zero}, nxt[3];
+  constexpr int CH[3] = {C0, C1, C2};
+  auto issue = [&](f32x16 (&acc)[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int m = 0; m < CH[c]; ++m) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c][m], b[c][m], m == 0 ? zero : acc[c], 0, 0, 0);
+    }
+  };
+  auto consume = [&](const f32x16 (&acc)[3]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float av = acc[j % 3][(j / 3) % 16];
+      asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x[j % 16]) : "v"(av), "v"(c0), "v"(x[(j + 8) % 16]));
+    }
+  };
+  __syncthreads();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long deadline = r0 + ticks;
+  unsigned long long iters = 0, r1 = r0;
+  issue(cur);
+  while (r1 < deadline) {
+#pragma unroll 1
+    for (int rep = 0; rep < 2; ++rep) {
+      issue(nxt);
+      consume(cur);
+      issue(cur);
+      consume(nxt);
+    }
+    iters += 4;
+    r1 = __builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float r = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r += x[i] + cur[0][i];
+  if (r == 12345.678f) out[0].iters = 1;
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = Rec{iters, t1 - t0, r1 - r0};
+}
+
+template <int C0, int C1, int C2, int N, int LB = 512>
+int run_chain_pipelined(int w, const uint4* in, Rec* out) {
+  const int blocks = 256, threads = 256 * w, waves = blocks * threads / 64;
+  if (threads > LB) return 0;  // the register budget of this instantiation does not hold that many waves
+  kchain_pipelined<C0, C1, C2, N, LB><<<blocks, threads>>>(out, in, 100000ull * 300);
+  CHECK(hipDeviceSynchronize());
+  std::vector<Rec> h(waves);
+  CHECK(hipMemcpy(h.data(), out, sizeof(Rec) * waves, hipMemcpyDeviceToHost));
+  double it = 0, cyc = 0;
+  std::vector<double> clk;
+  for (auto& r : h) { it += (double)r.iters; cyc += (double)r.cycles; clk.push_back((double)r.cycles / (double)r.ticks * 0.1); }
+  std::sort(clk.begin(), clk.end());
+  const double per_simd_it = it / 1024.0, mean_cyc = cyc / waves;
+  constexpr int M = C0 + C1 + C2;
+  printf("pipelined chains %d+%d+%d MFMA + N=%3d v_fma (VOP3)  waves/SIMD %d: %7.1f cycles per iteration per SIMD (issue bound %4d = %.2f of it; matrix pipe %4d = %.2f of it), held clock %.3f GHz\n",
+         C0, C1, C2, N, w, mean_cyc / per_simd_it, 2 * N + 8 * M, (2 * N + 8 * M) / (mean_cyc / per_simd_it), 32 * M, 32 * M / (mean_cyc / per_simd_it), clk[clk.size() / 2]);
+  fflush(stdout);
+  return 0;
+}
+
 template <int C0, int C1, int C2, int N>
 int run_chain(int w, const uint4* in, Rec* out) {
   const int blocks = 256, threads = 256 * w, waves = blocks * threads / 64;
@@ -161,6 +241,24 @@ int main(int argc, char**) {
     v = lo | (hi << 16);
   }
   CHECK(hipMemcpy(in, h.data(), 8192, hipMemcpyHostToDevice));
+  if (argc > 2) {  // the software-pipelined chained shapes only
+    for (int w : {1, 2}) {
+      if (run_chain_pipelined<4, 2, 2, 160>(w, in, out)) return 1;
+      if (run_chain_pipelined<4, 1, 1, 160>(w, in, out)) return 1;
+      if (run_chain_pipelined<1, 1, 1, 144>(w, in, out)) return 1;
+      if (run_chain_pipelined<1, 1, 1, 288>(w, in, out)) return 1;
+    }
+    if (run_chain_pipelined<4, 1, 1, 160, 768>(3, in, out)) return 1;  // 156 registers: three waves fit
+    for (int w : {3, 4}) {                                             // 118 registers: four waves fit
+      if (run_chain_pipelined<1, 1, 1, 144, 1024>(w, in, out)) return 1;
+      if (run_chain_pipelined<1, 1, 1, 288, 1024>(w, in, out)) return 1;
+    }
+    for (int w : {1, 2, 3}) {
+      if (run_chain<4, 2, 2, 160>(w, in, out)) return 1;
+      if (run_chain<1, 1, 1, 144>(w, in, out)) return 1;
+    }
+    return 0;
+  }
   if (argc > 1) {  // the chained shapes only
     for (int w : {2, 3, 4}) {
       if (run_chain<4, 1, 1, 160>(w, in, out)) return 1;
