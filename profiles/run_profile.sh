@@ -26,6 +26,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- pyt
 # memory traffic of the scoring kernels, one launch at a time against known byte counts (profiles/tools/traffic_probe.py)
 [ $rc -eq 0 ] && { timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/probe_fetch -o p -- python3 $R/profiles/tools/traffic_probe.py run > $OUT/probe_fetch.log 2>&1 || rc=7; }
 [ $rc -eq 0 ] && { timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/probe_write -o p -- python3 $R/profiles/tools/traffic_probe.py run > $OUT/probe_write.log 2>&1 || rc=8; }
+[ $rc -eq 0 ] && { timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/probe_trace -o trace -- python3 $R/profiles/tools/traffic_probe.py run > $OUT/probe_trace.log 2>&1 || rc=9; }
 [ $rc -eq 0 ] && python3 $R/profiles/tools/traffic_probe.py collect $OUT/probe_fetch $OUT/probe_write $OUT/traffic.json > $OUT/traffic.txt
 python3 $R/profiles/summarize.py $OUT $OUT/counters.json > $OUT/summary.txt
 find $OUT -name "*.db" -delete

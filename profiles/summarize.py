@@ -62,6 +62,42 @@ def main(d, json_out=None):
                 print(f"{'':80s} |   last {len(tail)} full-size launches (bench times these one at a time with events; earlier ones may "
                       f"overlap with another stream's launch): avg {sum(tail) / len(tail):.1f} us")
                 counters.setdefault(name, {})["trace_avg_us_last_full_size"] = sum(tail) / len(tail)
+            # The exact E/H scorer as ONE CALL: bench.py times sfm_eh_score_mixed with events, one call after the other on one
+            # stream; in the trace those are the launches of eh_score_mfma2_kernel that no other launch of a scoring kernel
+            # overlaps (the timed steps keep two calls in flight on two streams, which stretches both).
+            big = [(name, st, en) for name, st, en in rows if any(k in name for k in ("eh_score_mfma", "eh_upper_mfma", "eh_score_kernel", "eh_upper_kernel"))]
+            alone = {}
+            for i, (name, st, en) in enumerate(big):
+                if "eh_score_mfma2" not in name:
+                    continue
+                j = i - 1
+                hit = False
+                while j >= 0 and big[j][1] > st - 50_000_000:  # dispatches are ordered by start: look back 50 ms
+                    if big[j][2] > st:
+                        hit = True
+                        break
+                    j -= 1
+                if not hit and i + 1 < len(big) and big[i + 1][1] < en:
+                    hit = True
+                if not hit:
+                    alone.setdefault(name[:60], []).append((en - st) / 1e3)
+            if alone:
+                print("\n== launches of the exact E/H scorer that run alone on the device (us): instantiation | launches by duration group: count x average ==")
+                call = 0.0
+                for name, durs in alone.items():
+                    groups = clusters([(0.0, x * 1e3) for x in durs])
+                    txt = "  ".join(f"{g[2]} x {g[0]:.1f}" for g in groups)
+                    print(f"{name:60s} | {txt}")
+                    # the groups of the default workload: the most frequent long group (main launch) and, for the E launch, the most frequent short one (its last round)
+                    main = max((g for g in groups if g[0] > 1000.0), key=lambda g: g[2], default=None)
+                    tail = max((g for g in groups if g[0] < 400.0), key=lambda g: g[2], default=None)
+                    if main:
+                        call += main[0]
+                    if tail and "true, false" in name:
+                        call += tail[0]
+                if call:
+                    print(f"one call on the default workload = E main launch + E last round + H launch: {call:.1f} us (bench.py roofline.kernel_ms also holds the operand preparation, ~10 us)")
+                    counters["__exact_call_alone_us"] = {"sum_of_launches_us": call}
         except Exception as e:  # schema differences between rocprofv3 versions
             print("  (per-dispatch listing unavailable:", e, ")")
     for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
@@ -92,6 +128,29 @@ def main(d, json_out=None):
             small = [x for x, d_ in vals if d_ < 0.5 * min(d for _, d in big)]
             counters[name[:80]][cn + "__per_call"] = (sum(x for x, _ in big) + sum(small)) / len(big)
             counters[name[:80]].setdefault("__clusters", {})[cn] = clusters(vals)
+    pt = glob.glob(os.path.join(d, "probe_trace", "*.db"))
+    if pt:
+        c = sqlite3.connect(pt[0])
+        print("\n== kernel trace of profiles/tools/traffic_probe.py (each scoring call of the default workloads alone, a device synchronisation after "
+              "every call: durations without another stream's launch beside them): name | launches | avg us of the launches after the first ==")
+        try:
+            per = {}
+            for name, st, en in c.execute("select name, start, end from kernels order by start"):
+                if any(k in name for k in ("eh_score_mfma", "eh_upper_mfma", "t_score_mfma", "corr_to_mfma", "t_prep_mfma")):
+                    per.setdefault(name[:100], []).append((en - st) / 1e3)
+            total = {}
+            for name, durs in per.items():
+                # one kernel name may stand for the main launch and the cut-off last round of a call: group by duration
+                groups = clusters([(0.0, x * 1e3) for x in durs])
+                for avg_us, _, cnt in groups:
+                    print(f"{name:100s} | {cnt:4d} | {avg_us:10.1f}")
+                key = "exact E/H call (eh_score_mfma2: E main + E last round + H)" if "eh_score_mfma2" in name else None
+                if key:
+                    total[key] = total.get(key, 0.0) + sum(g[0] for g in groups)
+            for k, v in total.items():
+                print(f"sum of the launches of one {k}: {v:.1f} us")
+        except Exception as e:
+            print("  (unavailable:", e, ")")
     if json_out:
         with open(json_out, "w") as f:
             json.dump(counters, f, indent=1, sort_keys=True)
