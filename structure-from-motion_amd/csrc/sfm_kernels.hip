@@ -475,13 +475,6 @@ __device__ __forceinline__ float min3_abs(float m, float a, float b) {
   return r;
 }
 
-// min(m, a, b) in one instruction; a NaN operand is ignored, as by fminf
-__device__ __forceinline__ float min3_f32(float m, float a, float b) {
-  float r;
-  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
-  return r;
-}
-
 // kFloatCount: test outcomes are produced as 0.0f / 1.0f by the output clamp of the test's last instruction and summed
 // with float adds (both full-rate instructions; v_alignbit_b32, like v_min/v_max/v_add3/v_cmp, issues at half rate on
 // gfx950: profiles/microbench/valu_issue_probe).  For that the models are scaled by 2^40 (E) and 2^44 (H) on top of the
