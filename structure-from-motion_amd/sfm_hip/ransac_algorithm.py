@@ -153,13 +153,18 @@ def _draw(n, nb):
     return mark, legacy_rng.randint(n, 12 * nb).reshape(nb, 12)
 
 
-def run_replay(n, backend, chunk0=4096, chunk_max=1 << 18, max_iterations=None):
+AHEAD_MIN_PAIRS = 1 << 24  # draw the next block during the scoring of this one only when scoring takes longer than drawing
+
+
+def run_replay(n, backend, chunk0=512, chunk_max=1 << 18, max_iterations=None, ahead_min_pairs=AHEAD_MIN_PAIRS):
     """Draws index blocks from np.random, scores them through `backend` and replays the state
     machine; rewinds the stream so that exactly 12 integers per executed iteration are consumed.
 
     A backend with submit/collect scores a block asynchronously: the next block's index sets are drawn on the host
     while the GPU works (sized as if the block in flight ran to its end; a loop that ends earlier just leaves more
-    to rewind)."""
+    to rewind).  Drawing a sample costs the host about 50 ns, scoring it against a thousand matches costs the GPU about
+    1 ns: on small problems the draws ARE the loop, so the first block is small (loops on real image pairs end after
+    60-900 iterations) and nothing is drawn ahead until a block holds ahead_min_pairs (hypothesis, match) pairs."""
     st = ReplayState(n)
     chunk = chunk0
     nb = _block_size(st.it, st.limit(), chunk, max_iterations)
@@ -169,7 +174,7 @@ def run_replay(n, backend, chunk0=4096, chunk_max=1 << 18, max_iterations=None):
         nb = idx.shape[0]
         handle = backend.submit(idx, st.best_E, st.best_H) if hasattr(backend, "submit") else None
         chunk = min(chunk * 2, chunk_max)
-        nb_ahead = _block_size(st.it + nb, st.limit(), chunk, max_iterations)
+        nb_ahead = _block_size(st.it + nb, st.limit(), chunk, max_iterations) if handle is not None and nb * n >= ahead_min_pairs else 0
         nxt = _draw(n, nb_ahead) if nb_ahead else None  # speculative: overlaps with the scoring of this block
         exact = None
         if handle is not None:

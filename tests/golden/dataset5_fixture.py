@@ -8,7 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def load_fixture():
-    g = np.load(os.path.join(HERE, "dataset5_geometry.npz"), allow_pickle=False)
+    with np.load(os.path.join(HERE, "dataset5_geometry.npz"), allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}  # in memory: the stand-in matcher must not decompress the file on every call
     K = [[float(v) for v in row] for row in g["K"]]
     x_pairs = [g[f"x_pair_{k}"] for k in range(18)]
     desc = g["init_pair_desc"].astype(np.float32)

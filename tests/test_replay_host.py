@@ -167,7 +167,7 @@ def test_draw_ahead_replay_reproduces_reference_runs(golden, tag, chunk0, chunk_
     x2 = orc.normalize_K(sc["K"], sc["x2"])
     np.random.seed(int(g[f"{tag}_seed"]))
     be = AsyncOracleBackend(x1, x2, 1.0 / sc["K"][0][0])
-    st = run_replay(int(n), be, chunk0=chunk0, chunk_max=chunk_max)
+    st = run_replay(int(n), be, chunk0=chunk0, chunk_max=chunk_max, ahead_min_pairs=0)
     assert be.submitted > 0
     assert be.submitted == be.collected + getattr(be, "discarded", 0)  # every block in flight is collected or waited for
     assert st.it == len(g[f"{tag}_cH"])
@@ -183,7 +183,7 @@ def test_draw_ahead_replay_honours_an_iteration_cap():
     x2 = orc.normalize_K(sc["K"], sc["x2"])
     for cap in (1, 63, 64, 65, 200):
         np.random.seed(9)
-        st = run_replay(400, AsyncOracleBackend(x1, x2, 1.0 / sc["K"][0][0]), chunk0=64, max_iterations=cap)
+        st = run_replay(400, AsyncOracleBackend(x1, x2, 1.0 / sc["K"][0][0]), chunk0=64, max_iterations=cap, ahead_min_pairs=0)
         after = np.random.randint(0, 1 << 30, 2)
         np.random.seed(9)
         np.random.randint(0, 400, size=12 * st.it)
