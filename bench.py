@@ -345,7 +345,7 @@ def secondary_measurements(torch, ops, _capi, synthetic, seed, table=None):
         "best_counts": [int(c) for c in cnt],
         "roofline": {
             "bound": "valu_fp32",
-            "kernel": "t_score_mfma_kernel (dx, dy and thr*pz on the bf16 matrix cores, float32 sign test, float64 inside the error band; "
+            "kernel": "t_score_mfma_kernel (dx - thr*pz, dy and dx + thr*pz on the bf16 matrix cores, float32 sign test of their product form, float64 inside the error band; "
             "evaluates the reference's reprojection test for every pair); kernel_ms is the whole call (operand preparation, arg-max and winner "
             "kernels included: microseconds)",
             "kernel_ms": ms_mixed,

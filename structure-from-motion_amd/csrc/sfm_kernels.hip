@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   const bool all_f64 = !(xm < 1.0e4);  // no usable coordinate bound (or float32 products that could overflow): every pair takes the float64 test
   uint4(*bstage)[4][2] = reinterpret_cast<uint4(*)[4][2]>(&stage_raw[wave][0]);  // [lane][vector of the round][half]
   double Ed[9], Hd[9];
-  float ea_own = 0.0f, eb_own = 0.0f, ec_own = 0.0f, gh_own = 0.0f;
+  float ea_own = 0.0f, eb_own = 0.0f, gh_own = 0.0f;
   bf16x8 BE[2][kDoE ? 8 : 1], BH[2][kDoH ? 3 : 1];
   {
     double p8[8][4], p4[4][4];
@@ -1135,9 +1135,11 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     const double cB = es * es + 6.0 * k * eS + u * k * (Lb2 + 4.0 * eS);
     const double cC = 3.0 * eS;
     const double infl = safety * (1.0 + 0x1.0p-18);
+    // A pair whose float32 sign is wrong has s_c^2 <= k S_c / 2 + 2 es^2 (computed inlier: s_c^2 S_c < k n1_c n2_c <= k S_c^2 / 4;
+    // true inlier: s_c^2 <= 2 s^2 + 2 es^2 and s^2 < k n1 n2 / (n1 + n2) <= k S / 4), and S_c >= eS: the s^2 term cC s_c^2 of
+    // the band is therefore below S_c (cC k / 2 + 6 es^2) and rides in the constant term.
     ea_own = round_up_f32(cA * infl);
-    eb_own = round_up_f32(cB * infl);
-    ec_own = round_up_f32(cC * infl);
+    eb_own = round_up_f32((cB + 1.001 * cC * k / 2.0 + 6.01 * infl * es * es) * infl);
     n2_offset = 2.0 * eS;
     // round 1: the four vectors of s
     pack_pieces(e[0], e[1], 0.0, true, bstage[lane][0][0], bstage[lane][0][1]);
@@ -1162,22 +1164,23 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     const double inv = to_unit_f32(Hd, unused, A);
     const double R0 = xm * (A[0] + A[1]) + A[2], R1 = xm * (A[3] + A[4]) + A[5], R2 = xm * (A[6] + A[7]) + A[8];
     const double rt = sqrt(thr_h2);
-    const double Dx = (kEpsMfma + 3.0 * kEps32) * (R0 + xm * R2), Dy = (kEpsMfma + 3.0 * kEps32) * (R1 + xm * R2);
-    const double eq = rt * (kEpsMfma + 2.0 * kEps32) * R2;
-    const double e = safety * (Dx + Dy + eq);
-    // |dH_c| of a pair that the float32 sign may get wrong is below (4 e + 13 eps Q) |q_c| + 4.1 e^2 with |q_c| <= Q + e, Q = sqrt(T) R2
-    const double Q = rt * R2, c1 = 4.0 * e + 13.0 * kEps32 * Q * 1.001;
-    gh_own = !(xm < 1.0e5) ? __builtin_inff() : round_up_f32((c1 * (Q * 1.000001 + e) + 4.1 * e * e) * 1.000001);
+    // The test value is d = dx^2 + dy^2 - q^2 = P M + dy^2 with P = dx - q = x2 hz - (hx + rt hz), M = P + 2 q: the first
+    // vector carries hx + rt hz.  e bounds |P_c - P|, |M_c - M| and |dy_c - dy| (matrix-core error of the rows, float32
+    // rounding of x2, y2, 2 rt and of the three fused multiply-adds); the band follows as in t_score_mfma_kernel with
+    // Q = rt |hz| at its bound over all matches.
+    const double e = safety * (kEpsMfma + 4.0 * kEps32) * (fmax(R0, R1) + (xm + 3.0 * rt) * R2) * 1.001;
+    const double Q = rt * R2;
+    gh_own = !(xm < 1.0e5) ? __builtin_inff() : round_up_f32(1.001 * (4.0 * Q * e + 2.01 * kEps32 * Q * Q + 30.1 * e * e));
+    pack_pieces((Hd[0] + rt * Hd[6]) * inv, (Hd[1] + rt * Hd[7]) * inv, (Hd[2] + rt * Hd[8]) * inv, true, bstage[lane][0][0], bstage[lane][0][1]);
 #pragma unroll
-    for (int v = 0; v < 3; ++v) pack_pieces(Hd[3 * v] * inv, Hd[3 * v + 1] * inv, Hd[3 * v + 2] * inv, true, bstage[lane][v][0], bstage[lane][v][1]);
+    for (int v = 1; v < 3; ++v) pack_pieces(Hd[3 * v] * inv, Hd[3 * v + 1] * inv, Hd[3 * v + 2] * inv, true, bstage[lane][v][0], bstage[lane][v][1]);
     fetch_round(BH, 0, 3);
   }
-  float ea[2], eb[2], ec[2], gh[2];
+  float ea[2], eb[2], gh[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     ea[k] = __shfl(ea_own, 32 * k + col);
     eb[k] = __shfl(eb_own, 32 * k + col);
-    ec[k] = __shfl(ec_own, 32 * k + col);
     gh[k] = __shfl(gh_own, 32 * k + col);
   }
   qcnt[wave][0][lane] = 0;
@@ -1200,7 +1203,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     if constexpr (kDoH) parked[64 * 3 + lane] = __builtin_bit_cast(uint4, BH[0][kDoH ? 2 : 0]);
   }
   __syncthreads();
-  const float kinv = (float)(1.0 / two_thr_e2), rtf = (float)sqrt(thr_h2);
+  const float kinv = (float)(1.0 / two_thr_e2), two_rt = (float)(2.0 * sqrt(thr_h2));
   const int apos = 16 * ((col >> 2) & 1) + (col & 3) + 4 * (col >> 3);  // see eh_upper_mfma_kernel
   const int ntiles = (n + 31) / 32;
   const int t0 = blockIdx.y * tiles_per_split;
@@ -1311,7 +1314,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
           const float P = n1[i] * n2[i];
           const float dv = fma(s2, S, -P);  // < 0 <=> inlier
           const float w = fma(fabsf(sv[i]), ea[k], eb[k]);
-          const float rv = fma(-ec[k], s2, fma(-S, w, fabsf(dv)));  // < 0 <=> the float32 sign of dv is not trusted
+          const float rv = fma(-S, w, fabsf(dv));  // < 0 <=> the float32 sign of dv is not trusted
           hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(dv), 31);
           hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(rv), 31);
         }
@@ -1335,11 +1338,11 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
         const f32x16 hy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, h1, zero, 0, 0, 0);
         const f32x16 hz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, h2, zero, 0, 0, 0);
         if (k == 1) load_tile(src);
-        auto dH = [&](int i) {  // < 0 <=> inlier
-          const float dx = fma(x2[i], hz[i], -hx[i]);
+        auto dH = [&](int i) {  // < 0 <=> inlier (hx holds hx + rt hz)
+          const float P = fma(x2[i], hz[i], -hx[i]);
+          const float M = fma(two_rt, hz[i], P);
           const float dy = fma(y2[i], hz[i], -hy[i]);
-          const float q = rtf * hz[i];
-          return fma(-q, q, fma(dy, dy, dx * dx));
+          return fma(P, M, dy * dy);
         };
         // the band is one constant per hypothesis: the loop keeps the smallest |dH| of the row (half a v_min3 per pair) and
         // only a wave in which some row trips the band looks for the pairs (all its lanes walk that block: no lane waits)
@@ -2014,16 +2017,20 @@ __global__ __launch_bounds__(kBlock) void t_upper_kernel(const double* __restric
 // ---------------------------------------------------------------------------------------
 // Translation RANSAC with EXACT float64 counts at matrix-core + float32 cost.
 //   dx = (rx - u rz) + tx - u tz,  dy = (ry - v rz) + ty - v tz,  q = thr (rz + tz)
-// are bilinear in (hypothesis, correspondence), so each is one bf16 MFMA per 32 x 32 pairs from
-// three-piece splits (same expansion and error bound as in eh_upper_mfma_kernel); the float32 value
-// d = dx^2 + dy^2 - q^2 then decides the pair by its sign unless |d| <= delta, the rigorous bound of
-// its distance from the float64 value near the threshold: with r = |(dx, dy)| and e the bound of
-// |r_c - r| + |q_c - q|, a pair with |r - |q|| > e is decided correctly by the sign of r_c - |q_c|,
-// and any other pair has |d_c| <= 4 e |q_c| + 4 e^2 (+ float32 rounding of d_c) <= delta, where delta takes
-// |q_c| at its bound over the camera's correspondences and is therefore ONE constant per hypothesis: the inner
+// are bilinear in (hypothesis, correspondence), and so are P = dx - q and M = dx + q: P, M and dy are one bf16 MFMA
+// each per 32 x 32 pairs from three-piece splits (same expansion and error bound as in eh_upper_mfma_kernel), and the
+// test value d = dx^2 + dy^2 - q^2 = P M + dy^2 costs two float32 instructions per pair.  Its sign decides the pair
+// unless |d_c| <= delta, a rigorous bound of |d_c - d| for any pair whose sign could be wrong:
+//   with e >= |P_c - P|, |M_c - M|, |dy_c - dy|, r = |(dx, dy)|, Q = |q| and u = 2^-24,
+//   |P_c M_c + dy_c^2 - d| <= (|P| + |M| + 2 |dy| + 4 e) e + 2 e^2 <= (2 max(r, Q) + 2 r) e + 6 e^2  =: m,
+//   |d_c - d| <= (m (1 + u) + 1.001 u (r + e)^2) / (1 - u);
+//   a wrong sign needs |d| <= |d_c - d|; for r = Q + x, x >= 6 e + 2 u Q, d = x (2 Q + x) exceeds that bound, so
+//   r < Q (1 + 2 u) + 6 e, and then |d_c| <= |d_c - d| <= 4 Q e + 2.01 u Q^2 + 30.1 e^2 (times 1.001 for the rounding of the
+//   float64 test itself, which is 2^-26 of these terms).
+// delta takes Q at its bound over the camera's correspondences and is therefore ONE constant per hypothesis: the inner
 // loop only keeps the smallest |d_c| of a register row (half a v_min3 per pair) and compares it with delta once per
-// 16 pairs.  Pairs inside the band (about one in 10^6) are then found and re-evaluated with the float64 test of
-// t_score_kernel on the spot, so the counts are identical to t_score_kernel's for every hypothesis.
+// 16 pairs.  Pairs inside the band (about one in 10^6) are queued and re-evaluated with the float64 test of
+// t_score_kernel, so the counts are identical to t_score_kernel's for every hypothesis.
 // ---------------------------------------------------------------------------------------
 struct CamPad {
   int64_t poff[kMaxCams + 1];  // offsets of the cameras in the padded (multiple of 32) point numbering
@@ -2065,7 +2072,7 @@ __device__ __forceinline__ void pack_t_vector(bool lead_ones, double lead, bool 
   pack16(e, lo, hi);
 }
 
-// grid = (padded point blocks, cameras).  pieces[P][3][2]: the match-side vectors of dx, dy and q;
+// grid = (padded point blocks, cameras).  pieces[P][3][2]: the match-side vectors of P = dx - q, dy and M = dx + q;
 // maxima[cam][4] = max |rx - u rz|, |ry - v rz|, |rz|, max(|u|, |v|) as float32 bit patterns (rounded up).
 __global__ __launch_bounds__(kBlock) void t_prep_mfma_kernel(const double* __restrict__ pts_all, CamOffsets offs, CamPad pads, double thr,
                                                              uint4* __restrict__ pieces, unsigned* __restrict__ maxima) {
@@ -2080,9 +2087,9 @@ __global__ __launch_bounds__(kBlock) void t_prep_mfma_kernel(const double* __res
       const double* p = pts_all + 6 * (offs.off[cam] + j);
       const double rx = p[0], ry = p[1], rz = p[2], u = p[3], v = p[4];
       const double a = fma(-u, rz, rx), b = fma(-v, rz, ry);
-      pack_t_vector(false, a, true, 0.0, true, -u, false, out[0], out[1]);
+      pack_t_vector(false, a - thr * rz, true, 0.0, true, -u, false, out[0], out[1]);
       pack_t_vector(false, b, true, 0.0, true, -v, false, out[2], out[3]);
-      pack_t_vector(false, thr * rz, true, 0.0, false, 0.0, false, out[4], out[5]);
+      pack_t_vector(false, a + thr * rz, true, 0.0, true, -u, false, out[4], out[5]);
       mx[0] = f32_up_bits(fabs(a));
       mx[1] = f32_up_bits(fabs(b));
       mx[2] = f32_up_bits(fabs(rz));
@@ -2153,15 +2160,16 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
     const double zmax = __uint_as_float(maxima[4 * cam + 2]), uvmax = __uint_as_float(maxima[4 * cam + 3]);
     const double Rx = amax + fabs(T[0]) + uvmax * fabs(T[2]), Ry = bmax + fabs(T[1]) + uvmax * fabs(T[2]);
     const double Rq = thr * (zmax + fabs(T[2]));
-    usable = usable && Rx + Ry + Rq < 1.0e15;  // beyond that the float32 squares could overflow (false for NaN as well)
-    const double e = 2.0 * kEpsMfma * (Rx + Ry + Rq);  // bound of |r_c - r| + |q_c - q|, doubled
-    // |d_c| of a pair that the float32 sign may get wrong is below (4 e + 13 eps Rq) |q_c| + 4.1 e^2, and |q_c| <= Rq + e
-    const double c1 = 4.0 * e + 13.0 * kEps32 * Rq * 1.001;
-    band_own = usable ? round_up_f32((c1 * (Rq * 1.000001 + e) + 4.1 * e * e) * 1.000001) : __builtin_inff();
+    // beyond the first limit the float32 products could overflow (false for NaN as well), below the second they could underflow
+    usable = usable && Rx + Ry + Rq < 1.0e15 && fmax(Rx, Ry) + Rq > 1.0e-9;
+    // every row sum of |a||x| of the three forms is below max(Rx, Ry) + Rq (the last factor: float64 rounding of the operands)
+    const double e = kEpsMfma * (fmax(Rx, Ry) + Rq) * 1.000001;
+    const double u = kEps32;
+    band_own = usable ? round_up_f32(1.001 * (4.0 * Rq * e + 2.01 * u * Rq * Rq + 30.1 * e * e)) : __builtin_inff();
     const double tx = usable ? T[0] : 0.0, ty = usable ? T[1] : 0.0, tz = usable ? T[2] : 0.0;
-    pack_t_vector(true, 0.0, false, tx, true, tz, true, bstage[wave][lane][0][0], bstage[wave][lane][0][1]);
+    pack_t_vector(true, 0.0, false, tx - thr * tz, true, tz, true, bstage[wave][lane][0][0], bstage[wave][lane][0][1]);
     pack_t_vector(true, 0.0, false, ty, true, tz, true, bstage[wave][lane][1][0], bstage[wave][lane][1][1]);
-    pack_t_vector(true, 0.0, false, thr * tz, false, 0.0, true, bstage[wave][lane][2][0], bstage[wave][lane][2][1]);
+    pack_t_vector(true, 0.0, false, tx + thr * tz, true, tz, true, bstage[wave][lane][2][0], bstage[wave][lane][2][1]);
   }
   __syncthreads();
   bf16x8 B[2][3];
@@ -2215,20 +2223,30 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
   };
   __builtin_amdgcn_s_setprio(0);
   SFM_STAMP_BEGIN();
-  for (int t = t0; t < t1; ++t, src += 192) {
-    const bf16x8 Ax = as_bf16x8(src[0]), Ay = as_bf16x8(src[2]), Aq = as_bf16x8(src[4]);
+  // The correspondence-side vectors are loaded one tile ahead: once the MFMAs of the second hypothesis group have been
+  // issued their registers are free, and the next tile's loads run under that group's vector work.
+  bf16x8 Ap, Ay, Am;
+  auto load_tile = [&](const uint4* p) {
+    Ap = as_bf16x8(p[0]);
+    Ay = as_bf16x8(p[2]);
+    Am = as_bf16x8(p[4]);
+  };
+  if (t0 < t1) load_tile(src);
+  for (int t = t0; t < t1; ++t) {
     const unsigned vmask = t == (m >> 5) ? tail_mask : 0xFFFFu;
+    if (t + 1 < t1) src += 192;  // the last tile loads itself again
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const f32x16 dx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ax, B[k][0], zero, 0, 0, 0);
+      const f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ap, B[k][0], zero, 0, 0, 0);
       const f32x16 dy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay, B[k][1], zero, 0, 0, 0);
-      const f32x16 q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq, B[k][2], zero, 0, 0, 0);
+      const f32x16 dm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, B[k][2], zero, 0, 0, 0);
+      if (k == 1) load_tile(src);
       unsigned hneg = 0;
       float closest = __builtin_inff();  // the smallest |d| of this lane's 16 pairs
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
-        const float d0 = fma(-q[i], q[i], fma(dy[i], dy[i], dx[i] * dx[i]));  // < 0 <=> inlier
-        const float d1 = fma(-q[i + 1], q[i + 1], fma(dy[i + 1], dy[i + 1], dx[i + 1] * dx[i + 1]));
+        const float d0 = fma(dp[i], dm[i], dy[i] * dy[i]);  // < 0 <=> inlier
+        const float d1 = fma(dp[i + 1], dm[i + 1], dy[i + 1] * dy[i + 1]);
         hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d0), 31);
         hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(d1), 31);
         closest = min3_abs(closest, d0, d1);
@@ -2239,7 +2257,7 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
         unsigned hamb = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float d = fma(-q[i], q[i], fma(dy[i], dy[i], dx[i] * dx[i]));  // the same instructions give the same value again
+          const float d = fma(dp[i], dm[i], dy[i] * dy[i]);  // the same instructions give the same value again
           hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(d) - band[k]), 31);  // <= 0 would be exact; < 0 after the inflation of band
         }
         const unsigned amb = band[k] == __builtin_inff() ? vmask : (hamb & vmask);  // an unusable hypothesis takes the float64 test everywhere
