@@ -469,6 +469,9 @@ __device__ __forceinline__ unsigned tile_tail_mask(int n, int half) {
 }
 
 // min(m, |a|, |b|) in one instruction (m >= 0); a NaN operand is ignored, as by fminf
+// the lanes whose condition holds (HIP's __ballot takes an int: the bool would first become 0 / 1 through a v_cndmask)
+__device__ __forceinline__ unsigned long long ballot64(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+
 __device__ __forceinline__ float min3_abs(float m, float a, float b) {
   float r;
   asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
@@ -1217,6 +1220,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   // on about half of all rows): their (match, hypothesis) ids are appended to a queue of the wave, and the queue is
   // worked off 64 pairs at a time with the float64 tests of eh_score_kernel; the verdicts are added to per-hypothesis
   // counters in LDS.  entry = match << 7 | test << 6 | hypothesis of the wave.
+  const unsigned force_f64 = all_f64 ? 0xFFFFu : 0u, force_h = !(xm < 1.0e5) ? 0xFFFFu : 0u;  // wave-uniform
   int qlen = 0;
   auto drain = [&]() {
     __builtin_amdgcn_wave_barrier();
@@ -1240,9 +1244,9 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     qlen = 0;
     __builtin_amdgcn_wave_barrier();
   };
-  auto enqueue = [&](unsigned amb, int hyp_of_wave, int test_h, int first_match) {  // called by the whole wave; bit 15-i of amb = match first_match + i
-    unsigned long long any = __ballot(amb != 0u);
-    while (any) {
+  // called by the whole wave with any = the lanes that have a pair to queue (not empty); bit 15-i of amb = match first_match + i
+  auto enqueue = [&](unsigned amb, unsigned long long any, int hyp_of_wave, int test_h, int first_match) {
+    do {
       const bool act = amb != 0u;
       const int bit = __ffs((int)amb) - 1;
       amb &= amb - 1u;
@@ -1251,8 +1255,8 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
       if (act) qbuf[wave][pos] = entry;
       qlen += __popcll(any);
       if (qlen > kQueue - 64) drain();
-      any = __ballot(amb != 0u);
-    }
+      any = ballot64(amb != 0u);
+    } while (any);
   };
   __builtin_amdgcn_s_setprio(0);
   SFM_STAMP_BEGIN();
@@ -1271,7 +1275,10 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   };
   if (t0 < t1) load_tile(src);
   for (int t = t0; t < t1; ++t, xsrc += 16) {
-    const unsigned vmask = t == (n >> 5) ? tail_mask : 0xFFFFu;
+    // (a v_cndmask costs 18 issue cycles of the SIMD on this chip: the per-tile masks are formed with scalar selects and an OR)
+    unsigned fill = t == (n >> 5) ? 0u : 0xFFFFu;
+    asm volatile("" : "+s"(fill));  // keeps the select scalar
+    const unsigned vmask = tail_mask | fill;
     if (t + 1 < t1) src += kEhxVecA * 64;  // the last tile loads itself again
     float x2[kDoH ? 16 : 1], y2[kDoH ? 16 : 1];
     if constexpr (kDoH) {
@@ -1318,7 +1325,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
           hneg = __builtin_amdgcn_alignbit(hneg, __float_as_uint(dv), 31);
           hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(rv), 31);
         }
-        amb_e = all_f64 ? vmask : (hamb & vmask);  // padding has dv = rv = -0 or +0: masked either way
+        amb_e = (hamb | force_f64) & vmask;  // padding has dv = rv = -0 or +0: masked either way
         ce[k] += __popc(hneg & vmask & ~amb_e);
       }
       if constexpr (kDoH) {
@@ -1356,20 +1363,20 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
           closest = min3_abs(closest, d0, d1);
         }
         ch[k] += __popc(hneg & vmask);
-        if (__ballot(closest <= gh[k])) {
+        if (ballot64(closest <= gh[k])) {
           unsigned hamb = 0;
 #pragma unroll
           for (int i = 0; i < 16; ++i) hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(dH(i)) - gh[k]), 31);  // the same values again
-          amb_h = !(xm < 1.0e5) ? vmask : (hamb & vmask);
+          amb_h = (hamb | force_h) & vmask;
           ch[k] -= __popc(hneg & amb_h);  // take the untrusted signs back out
         }
       }
       SFM_STAMP_COUNT((amb_e | amb_h) != 0u);
       if constexpr (kDoE) {
-        if (__ballot(amb_e != 0u)) enqueue(amb_e, 32 * k + col, 0, t * 32 + 16 * half);
+        if (const unsigned long long any = ballot64(amb_e != 0u)) enqueue(amb_e, any, 32 * k + col, 0, t * 32 + 16 * half);
       }
       if constexpr (kDoH) {
-        if (__ballot(amb_h != 0u)) enqueue(amb_h, 32 * k + col, 1, t * 32 + 16 * half);
+        if (const unsigned long long any = ballot64(amb_h != 0u)) enqueue(amb_h, any, 32 * k + col, 1, t * 32 + 16 * half);
       }
     }
   }
@@ -2174,11 +2181,13 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
   __syncthreads();
   bf16x8 B[2][3];
   float band[2];
+  unsigned force[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
 #pragma unroll
     for (int v = 0; v < 3; ++v) B[k][v] = as_bf16x8(bstage[wave][32 * k + col][v][half]);
     band[k] = __shfl(band_own, 32 * k + col);
+    force[k] = band[k] == __builtin_inff() ? 0xFFFFu : 0u;
   }
   const int apos = 16 * ((col >> 2) & 1) + (col & 3) + 4 * (col >> 3);  // see eh_upper_mfma_kernel
   const int ntiles = (m + 31) / 32;
@@ -2207,9 +2216,9 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
     qlen = 0;
     __builtin_amdgcn_wave_barrier();
   };
-  auto enqueue = [&](unsigned amb, int hyp_of_wave, int first) {  // called by the whole wave; bit 15-i of amb = correspondence first + i
-    unsigned long long any = __ballot(amb != 0u);
-    while (any) {
+  // called by the whole wave with any = the lanes that have a pair to queue (not empty); bit 15-i of amb = correspondence first + i
+  auto enqueue = [&](unsigned amb, unsigned long long any, int hyp_of_wave, int first) {
+    do {
       const bool act = amb != 0u;
       const int bit = __ffs((int)amb) - 1;
       amb &= amb - 1u;
@@ -2218,8 +2227,8 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
       if (act) qbuf[wave][pos] = entry;
       qlen += __popcll(any);
       if (qlen > kQueue - 64) drain();
-      any = __ballot(amb != 0u);
-    }
+      any = ballot64(amb != 0u);
+    } while (any);
   };
   __builtin_amdgcn_s_setprio(0);
   SFM_STAMP_BEGIN();
@@ -2233,7 +2242,9 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
   };
   if (t0 < t1) load_tile(src);
   for (int t = t0; t < t1; ++t) {
-    const unsigned vmask = t == (m >> 5) ? tail_mask : 0xFFFFu;
+    unsigned fill = t == (m >> 5) ? 0u : 0xFFFFu;  // scalar select + OR (a v_cndmask costs 18 issue cycles of the SIMD)
+    asm volatile("" : "+s"(fill));
+    const unsigned vmask = tail_mask | fill;
     if (t + 1 < t1) src += 192;  // the last tile loads itself again
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -2253,16 +2264,16 @@ __global__ __launch_bounds__(kBlock, 2) void t_score_mfma_kernel(const double* _
       }
       cnt[k] += __popc(hneg & vmask);
       SFM_STAMP_COUNT(closest <= band[k]);
-      if (__ballot(closest <= band[k])) {  // rare per row, not per wave: some pair of some lane's row is too close to the threshold (or is padding)
+      if (ballot64(closest <= band[k])) {  // rare per row, not per wave: some pair of some lane's row is too close to the threshold (or is padding)
         unsigned hamb = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float d = fma(dp[i], dm[i], dy[i] * dy[i]);  // the same instructions give the same value again
           hamb = __builtin_amdgcn_alignbit(hamb, __float_as_uint(fabsf(d) - band[k]), 31);  // <= 0 would be exact; < 0 after the inflation of band
         }
-        const unsigned amb = band[k] == __builtin_inff() ? vmask : (hamb & vmask);  // an unusable hypothesis takes the float64 test everywhere
+        const unsigned amb = (hamb | force[k]) & vmask;  // an unusable hypothesis takes the float64 test everywhere
         cnt[k] -= __popc(hneg & amb);  // take the untrusted signs back out
-        enqueue(amb, 32 * k + col, t * 32 + 16 * half);
+        if (const unsigned long long any = ballot64(amb != 0u)) enqueue(amb, any, 32 * k + col, t * 32 + 16 * half);
       }
     }
   }

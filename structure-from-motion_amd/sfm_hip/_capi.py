@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsfm_hip.so")
+# SFM_HIP_LIBRARY=<path> loads another build of the library (same-device comparisons of two builds within one job)
+LIB_PATH = os.environ.get("SFM_HIP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libsfm_hip.so")
 
 _c = ctypes
 _P = _c.c_void_p
