@@ -445,6 +445,46 @@ def test_mixed_translation_ransac_counts_are_identical_to_float64(ops, dev):
     assert 100 < int(c64[5, 0]) < 3900
 
 
+@pytest.mark.parametrize("scale", [1e-12, 1e-7, 1e-3, 1.0, 1e4, 1e9, 1e14, 1e20])
+@pytest.mark.parametrize("thr_px", [1e-6, 4.0, 2000.0])
+def test_mixed_translation_ransac_in_other_scales_and_thresholds(ops, dev, scale, thr_px):
+    """The same comparison with the scene (R X and hence T) scaled by powers of ten, from scales whose float32 products
+    underflow to ones where they overflow (those hypotheses take the float64 test everywhere), and with thresholds from a
+    millionth of a pixel to more than the image: every count equals the float64 kernel's at that scale."""
+    import torch
+
+    K = synthetic.K_DATASET5
+    thr = thr_px / K[0][0]
+    rng = np.random.default_rng(3)
+    sizes = [3000, 65]
+    packs = []
+    for i, m in enumerate(sizes):
+        c = synthetic.resection_scene(m=m, outlier_ratio=0.4, seed=70 + i)
+        p = ops.pack_points(dev(c["R"].ravel()), dev(c["X"]), dev(c["x_norm"])).cpu().numpy()
+        if i == 0 and thr_px == 4.0:  # a ring of projections next to the threshold circle of the true translation
+            proj = p[:, :3] + c["T_true"]
+            uv = proj[:, :2] / proj[:, 2:3]
+            ang = rng.uniform(0, 2 * np.pi, m)
+            rad = thr * (1.0 + rng.integers(-40, 41, m) * 1e-7)
+            p[:, 3] = uv[:, 0] + rad * np.cos(ang)
+            p[:, 4] = uv[:, 1] + rad * np.sin(ang)
+            p[:2, 3:5] = uv[:2]
+        p[:, :3] *= scale
+        packs.append(dev(p))
+    pts = torch.cat(packs)
+    B = 3000
+    idx_h = np.stack([rng.integers(0, m, size=(B, 2)) for m in sizes]).astype(np.int32)
+    idx_h[0, 0] = (0, 1)
+    idx = dev(idx_h)
+    b64, T64, c64 = ops.t_ransac(pts, sizes, idx, thr, mixed=False)
+    bmx, Tmx, cmx = ops.t_ransac(pts, sizes, idx, thr, mixed=True)
+    assert torch.equal(c64, cmx)
+    assert torch.equal(b64, bmx)
+    assert np.array_equal(T64.cpu().numpy(), Tmx.cpu().numpy(), equal_nan=True)
+    if thr_px == 4.0 and 1e-7 <= scale <= 1e9:
+        assert 100 < int(c64[0, 0]) < 2900  # the ring really has points on both sides of the circle
+
+
 @pytest.mark.parametrize("n,B,inl,pl,px,seed", [(1500, 20000, 0.5, 0.5, 1.0, 1), (10000, 60000, 0.3, 0.5, 1.0, 0), (97, 4099, 0.8, 1.0, 0.5, 2),
                                                 (12, 64, 0.9, 0.0, 3.0, 3), (5000, 3000, 0.0, 0.5, 1.0, 4), (2048, 257, 0.95, 0.5, 1.0, 5)])
 def test_mixed_eh_scoring_counts_are_identical_to_float64(ops, dev, n, B, inl, pl, px, seed):
