@@ -1131,7 +1131,11 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     const double C0 = xm * (A[0] + A[3]) + A[6], C1 = xm * (A[1] + A[4]) + A[7];
     const double Sb = xm * (R0 + R1) + R2, N1b = R0 * R0 + R1 * R1, N2b = C0 * C0 + C1 * C1, Lb2 = fmin(N1b, N2b);
     const double u = kEps32;
-    const double es = (2.0 + 32.0 * 4.0) * u * Sb;
+    // |s_c - s|: piece expansion 2 u Sb, and every MFMA of the chain adds at most 32 u (its own terms + what it is handed):
+    // the four MFMAs hold the terms of (x2 x1, x2 y1), (y2 x1, y2 y1), (x2, y2) and (x1, y1, 1) in this order, so the first
+    // group's magnitude is counted four times and the last one's once (2^-5: the lower-order piece products and the rounding of what is handed on)
+    const double es = (2.0 * Sb + 32.0 * (1.0 + 0x1.0p-5) * (4.0 * xm * xm * (A[0] + A[1]) + 3.0 * xm * xm * (A[3] + A[4]) + 2.0 * xm * (A[2] + A[5]) +
+                                                              (xm * (A[6] + A[7]) + A[8]))) * u;
     const double kn = 0x1.1p-18 + 66.0 * u;
     const double eS = kn * (N1b + N2b) * 1.0001;  // en1 + en2, the offset 2 eS of n2 (below) included in its bound
     const double cA = 2.0 * es + 3.1 * u * (Sb + es);
