@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma_kernel(const
 // collected (with 2 |s_c| es eS <= (s_c^2 + es^2) eS) as A = 2 es + 4.1 u (Sb + es), B = 3 es^2 + k en + u k Lb2, C = 2 eS,
 // T = the products of three error terms + an absolute floor, all doubled (safety) and rounded up.
 // ---------------------------------------------------------------------------------------
-constexpr int kEhxVecA = 6;  // match-side vectors per match: Sa, Sb, Q1, Q2, A1 = (x1, y1, 1), A2 = (x2, y2, 1)
+constexpr int kEhxVecA = 6;  // match-side vectors per match: Sa, Sb, N1, N2 (the monomials of n1, n2), A1 = (x1, y1, 1), A2 = (x2, y2, 1)
 
 // 5-term piece products of three monomials: hypothesis side (q0 q0 q1 q0 q2), match side (m0 m1 m0 m2 m0), 15 of 16 slots
 __device__ __forceinline__ void pack_quad(double a, double b, double c, bool model, uint4& lo, uint4& hi) {
@@ -1043,6 +1043,29 @@ __device__ __forceinline__ void pack_quad(double a, double b, double c, bool mod
   hi = make_uint4(e[8] | (e[9] << 16), e[10] | (e[11] << 16), e[12] | (e[13] << 16), e[14] | (e[15] << 16));
 }
 
+// A whole quadratic form a x^2 + b x y + c y^2 + d x + e y + f in ONE operand vector: three piece products (m0 c0, m1 c0, m0 c1)
+// for x^2, y^2, x and y, two (m0 c0, m0 c1) for x y and two for the constant (match side 1, 1).  Relative error of a kept
+// triple 3.1 * 2^-18, of the x y term 2^-9 * 1.01 (its second match-side piece is dropped), of the constant 2^-17.
+__device__ __forceinline__ void pack_form(double xx, double xy, double yy, double x, double y, double one, bool model, uint4& lo, uint4& hi) {
+  unsigned p[3], e[16];
+  const double three[4] = {xx, yy, x, y};
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    split3_bf16(three[m], p);
+    if (model) {
+      e[3 * m] = p[0]; e[3 * m + 1] = p[0]; e[3 * m + 2] = p[1];
+    } else {
+      e[3 * m] = p[0]; e[3 * m + 1] = p[1]; e[3 * m + 2] = p[0];
+    }
+  }
+  split3_bf16(xy, p);
+  e[12] = p[0]; e[13] = model ? p[1] : p[0];
+  split3_bf16(one, p);
+  e[14] = p[0]; e[15] = model ? p[1] : p[0];
+  lo = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+  hi = make_uint4(e[8] | (e[9] << 16), e[10] | (e[11] << 16), e[12] | (e[13] << 16), e[14] | (e[15] << 16));
+}
+
 // pieces[tile][vector][match of the tile][half]: a wave's load of one vector of one tile is 1 KB of consecutive bytes
 __global__ __launch_bounds__(kBlock) void corr_to_mfma3_kernel(const double4* __restrict__ corr, int n, int npad, uint4* __restrict__ pieces,
                                                                float2* __restrict__ xy) {
@@ -1054,8 +1077,8 @@ __global__ __launch_bounds__(kBlock) void corr_to_mfma3_kernel(const double4* __
       c = corr[j];
       pack_pieces(c.z * c.x, c.z * c.y, 1.0, false, out[0], out[1]);
       pack_pieces(c.w * c.x, c.w * c.y, 1.0, false, out[64], out[65]);
-      pack_quad(c.x * c.x, c.x * c.y, c.y * c.y, false, out[128], out[129]);
-      pack_quad(c.z * c.z, c.z * c.w, c.w * c.w, false, out[192], out[193]);
+      pack_form(c.x * c.x, c.x * c.y, c.y * c.y, c.x, c.y, 1.0, false, out[128], out[129]);
+      pack_form(c.z * c.z, c.z * c.w, c.w * c.w, c.z, c.w, 1.0, false, out[192], out[193]);
       pack_pieces(c.x, c.y, 1.0, false, out[256], out[257]);
       pack_pieces(c.z, c.w, 1.0, false, out[320], out[321]);
       xy[j] = make_float2((float)c.z, (float)c.w);
@@ -1076,7 +1099,8 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
                                                                             int* __restrict__ count_h, int tiles_per_split, int use_atomics) {
   constexpr int kModel = 9 * ((kDoE ? 1 : 0) + (kDoH ? 1 : 0));  // doubles per hypothesis parked for the float64 re-evaluation
   constexpr bool kPark = kDoE != kDoH;          // a one-model instantiation keeps some piece vectors in LDS, see below
-  constexpr int kParked = kPark ? (kDoE ? 3 : 4) : 0;
+  constexpr int kParkedE = 0;  // piece vectors of the second hypothesis group that the E-only instantiation keeps in LDS
+  constexpr int kParked = kPark ? (kDoE ? kParkedE : 4) : 0;
   constexpr int kAfter = kModel * 8 * 64 + kParked * 16 * 64;  // the staging area later holds the float64 models and the parked vectors
   constexpr int kStageBytes = kAfter > 4 * 32 * 64 ? kAfter : 4 * 32 * 64;  // four piece vectors per round first
   constexpr int kQueue = 256;  // pairs whose float32 sign is not trusted wait here for a dense float64 pass (per wave)
@@ -1096,7 +1120,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   uint4(*bstage)[4][2] = reinterpret_cast<uint4(*)[4][2]>(&stage_raw[wave][0]);  // [lane][vector of the round][half]
   double Ed[9], Hd[9];
   float ea_own = 0.0f, eb_own = 0.0f, gh_own = 0.0f;
-  bf16x8 BE[2][kDoE ? 8 : 1], BH[2][kDoH ? 3 : 1];
+  bf16x8 BE[2][kDoE ? 6 : 1], BH[2][kDoH ? 3 : 1];
   {
     double p8[8][4], p4[4][4];
     gather_samples<double>(corr, n, idx + 12 * hyp, p8, p4);
@@ -1136,8 +1160,11 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     // group's magnitude is counted four times and the last one's once (2^-5: the lower-order piece products and the rounding of what is handed on)
     const double es = (2.0 * Sb + 32.0 * (1.0 + 0x1.0p-5) * (4.0 * xm * xm * (A[0] + A[1]) + 3.0 * xm * xm * (A[3] + A[4]) + 2.0 * xm * (A[2] + A[5]) +
                                                               (xm * (A[6] + A[7]) + A[8]))) * u;
-    const double kn = 0x1.1p-18 + 66.0 * u;
-    const double eS = kn * (N1b + N2b) * 1.0001;  // en1 + en2, the offset 2 eS of n2 (below) included in its bound
+    // n1 and n2 are one MFMA each: kept piece products 3.1 * 2^-18, accumulation 34 u, and the x y monomial with two of
+    // three products (2^-9 of its term, |x y| <= xm^2)
+    const double q1ab = 2.0 * fabs(fma(e[0], e[1], e[3] * e[4])), q2ab = 2.0 * fabs(fma(e[0], e[3], e[1] * e[4]));
+    const double kn = 3.1 * 0x1.0p-18 + 34.0 * u;
+    const double eS = (kn * (N1b + N2b) + 0x1.02p-9 * xm * xm * (q1ab + q2ab)) * 1.0001;  // en1 + en2, the offset 2 eS of n2 (below) included in its bound
     const double cA = 2.0 * es + 3.1 * u * (Sb + es);
     const double cB = es * es + 6.0 * k * eS + u * k * (Lb2 + 4.0 * eS);
     const double cC = 3.0 * eS;
@@ -1154,16 +1181,13 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     pack_pieces(e[2], e[5], 0.0, true, bstage[lane][2][0], bstage[lane][2][1]);
     pack_pieces(e[6], e[7], e[8], true, bstage[lane][3][0], bstage[lane][3][1]);
     fetch_round(BE, 0, 4);
-    // round 2: k n1 (quadratic and linear part), n2 (quadratic and linear part)
-    pack_quad(k * fma(e[0], e[0], e[3] * e[3]), 2.0 * k * fma(e[0], e[1], e[3] * e[4]), k * fma(e[1], e[1], e[4] * e[4]), true, bstage[lane][0][0],
+    // round 2: the quadratic forms k n1 and n2, one vector each
+    pack_form(k * fma(e[0], e[0], e[3] * e[3]), 2.0 * k * fma(e[0], e[1], e[3] * e[4]), k * fma(e[1], e[1], e[4] * e[4]),
+              2.0 * k * fma(e[0], e[2], e[3] * e[5]), 2.0 * k * fma(e[1], e[2], e[4] * e[5]), k * fma(e[2], e[2], e[5] * e[5]), true, bstage[lane][0][0],
               bstage[lane][0][1]);
-    pack_pieces(2.0 * k * fma(e[0], e[2], e[3] * e[5]), 2.0 * k * fma(e[1], e[2], e[4] * e[5]), k * fma(e[2], e[2], e[5] * e[5]), true,
-                bstage[lane][1][0], bstage[lane][1][1]);
-    pack_quad(fma(e[0], e[0], e[1] * e[1]), 2.0 * fma(e[0], e[3], e[1] * e[4]), fma(e[3], e[3], e[4] * e[4]), true, bstage[lane][2][0],
-              bstage[lane][2][1]);
-    pack_pieces(2.0 * fma(e[0], e[6], e[1] * e[7]), 2.0 * fma(e[3], e[6], e[4] * e[7]), fma(e[6], e[6], e[7] * e[7]) + n2_offset, true,
-                bstage[lane][3][0], bstage[lane][3][1]);
-    fetch_round(BE, 4, 4);
+    pack_form(fma(e[0], e[0], e[1] * e[1]), 2.0 * fma(e[0], e[3], e[1] * e[4]), fma(e[3], e[3], e[4] * e[4]), 2.0 * fma(e[0], e[6], e[1] * e[7]),
+              2.0 * fma(e[3], e[6], e[4] * e[7]), fma(e[6], e[6], e[7] * e[7]) + n2_offset, true, bstage[lane][1][0], bstage[lane][1][1]);
+    fetch_round(BE, 4, 2);
   }
   if constexpr (kDoH) {
     double A[9];
@@ -1205,9 +1229,14 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     if constexpr (kDoH) mstage[kModel * lane + (kDoE ? 9 : 0) + i] = Hd[i];
   }
   if constexpr (kPark) {
+    if constexpr (kDoE) {
 #pragma unroll
-    for (int v = 0; v < 3; ++v) parked[64 * v + lane] = __builtin_bit_cast(uint4, kDoE ? BE[1][kDoE ? 5 + v : 0] : BH[1][kDoH ? v : 0]);
-    if constexpr (kDoH) parked[64 * 3 + lane] = __builtin_bit_cast(uint4, BH[0][kDoH ? 2 : 0]);
+      for (int v = 0; v < kParkedE; ++v) parked[64 * v + lane] = __builtin_bit_cast(uint4, BE[1][kDoE ? 6 - kParkedE + v : 0]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < 3; ++v) parked[64 * v + lane] = __builtin_bit_cast(uint4, BH[1][kDoH ? v : 0]);
+      parked[64 * 3 + lane] = __builtin_bit_cast(uint4, BH[0][kDoH ? 2 : 0]);
+    }
   }
   __syncthreads();
   const float kinv = (float)(1.0 / two_thr_e2), two_rt = (float)(2.0 * sqrt(thr_h2));
@@ -1266,14 +1295,14 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   SFM_STAMP_BEGIN();
   // The match-side vectors of a tile are loaded one tile ahead: after the last MFMA of a tile has been issued their
   // registers are free, and the loads of the next tile then run under the vector work of the second hypothesis group.
-  bf16x8 A1, ASa, ASb, AQ1, AQ2, A2;
+  bf16x8 A1, ASa, ASb, AN1, AN2, A2;
   auto load_tile = [&](const uint4* q) {
     A1 = as_bf16x8(q[4 * 64]);
     if constexpr (kDoE) {
       ASa = as_bf16x8(q[0]);
       ASb = as_bf16x8(q[64]);
-      AQ1 = as_bf16x8(q[2 * 64]);
-      AQ2 = as_bf16x8(q[3 * 64]);
+      AN1 = as_bf16x8(q[2 * 64]);
+      AN2 = as_bf16x8(q[3 * 64]);
       A2 = as_bf16x8(q[5 * 64]);
     }
   };
@@ -1296,22 +1325,19 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     for (int k = 0; k < 2; ++k) {
       unsigned amb_e = 0, amb_h = 0;
       if constexpr (kDoE) {
-        bf16x8 b5 = BE[k][5], b6 = BE[k][6], b7 = BE[k][7];
-        if constexpr (kPark) {
+        bf16x8 bn[2] = {BE[k][4], BE[k][5]};
+        if constexpr (kPark && kParkedE > 0) {
           if (k == 1) {
             int at = lane;
             asm volatile("" : "+v"(at));  // keeps the reads inside the loop (hoisted, they would be spilled again)
-            b5 = as_bf16x8(parked[at]);
-            b6 = as_bf16x8(parked[64 + at]);
-            b7 = as_bf16x8(parked[128 + at]);
+#pragma unroll
+            for (int v = 0; v < kParkedE; ++v) bn[2 - kParkedE + v] = as_bf16x8(parked[64 * v + at]);
           }
         }
         f32x16 sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ASa, BE[k][0], zero, 0, 0, 0);
-        f32x16 n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ1, BE[k][4], zero, 0, 0, 0);
-        f32x16 n2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ2, b6, zero, 0, 0, 0);
+        const f32x16 n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AN1, bn[0], zero, 0, 0, 0);
         sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ASb, BE[k][1], sv, 0, 0, 0);
-        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, b5, n1, 0, 0, 0);
-        n2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, b7, n2, 0, 0, 0);
+        const f32x16 n2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AN2, bn[1], zero, 0, 0, 0);
         sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, BE[k][2], sv, 0, 0, 0);
         sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, BE[k][3], sv, 0, 0, 0);
         if constexpr (!kDoH) {
