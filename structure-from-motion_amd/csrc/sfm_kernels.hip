@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma_kernel(const
 // collected (with 2 |s_c| es eS <= (s_c^2 + es^2) eS) as A = 2 es + 4.1 u (Sb + es), B = 3 es^2 + k en + u k Lb2, C = 2 eS,
 // T = the products of three error terms + an absolute floor, all doubled (safety) and rounded up.
 // ---------------------------------------------------------------------------------------
-constexpr int kEhxVecA = 6;  // match-side vectors per match: Sa, Sb, N1, N2 (the monomials of n1, n2), A1 = (x1, y1, 1), A2 = (x2, y2, 1)
+constexpr int kEhxVecA = 6;  // match-side vectors per match: S1, S2 (six of the nine monomials of s), N1, N2 (the monomials of n1, n2), A1 = (x1, y1, 1) for the H test, S3 = (x1, y1, 1) in the five-product layout
 
 // 5-term piece products of three monomials: hypothesis side (q0 q0 q1 q0 q2), match side (m0 m1 m0 m2 m0), 15 of 16 slots
 __device__ __forceinline__ void pack_quad(double a, double b, double c, bool model, uint4& lo, uint4& hi) {
@@ -1075,12 +1075,12 @@ __global__ __launch_bounds__(kBlock) void corr_to_mfma3_kernel(const double4* __
     uint4* out = pieces + ((long long)(j >> 5) * (kEhxVecA * 32) + (j & 31)) * 2;  // vector v at out[64 v], out[64 v + 1]
     if (j < n) {
       c = corr[j];
-      pack_pieces(c.z * c.x, c.z * c.y, 1.0, false, out[0], out[1]);
-      pack_pieces(c.w * c.x, c.w * c.y, 1.0, false, out[64], out[65]);
+      pack_quad(c.z * c.x, c.z * c.y, c.w * c.x, false, out[0], out[1]);
+      pack_quad(c.w * c.y, c.z, c.w, false, out[64], out[65]);
       pack_form(c.x * c.x, c.x * c.y, c.y * c.y, c.x, c.y, 1.0, false, out[128], out[129]);
       pack_form(c.z * c.z, c.z * c.w, c.w * c.w, c.z, c.w, 1.0, false, out[192], out[193]);
       pack_pieces(c.x, c.y, 1.0, false, out[256], out[257]);
-      pack_pieces(c.z, c.w, 1.0, false, out[320], out[321]);
+      pack_quad(c.x, c.y, 1.0, false, out[320], out[321]);
       xy[j] = make_float2((float)c.z, (float)c.w);
     } else {
 #pragma unroll
@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   uint4(*bstage)[4][2] = reinterpret_cast<uint4(*)[4][2]>(&stage_raw[wave][0]);  // [lane][vector of the round][half]
   double Ed[9], Hd[9];
   float ea_own = 0.0f, eb_own = 0.0f, gh_own = 0.0f;
-  bf16x8 BE[2][kDoE ? 6 : 1], BH[2][kDoH ? 3 : 1];
+  bf16x8 BE[2][kDoE ? 5 : 1], BH[2][kDoH ? 3 : 1];
   {
     double p8[8][4], p4[4][4];
     gather_samples<double>(corr, n, idx + 12 * hyp, p8, p4);
@@ -1155,11 +1155,12 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     const double C0 = xm * (A[0] + A[3]) + A[6], C1 = xm * (A[1] + A[4]) + A[7];
     const double Sb = xm * (R0 + R1) + R2, N1b = R0 * R0 + R1 * R1, N2b = C0 * C0 + C1 * C1, Lb2 = fmin(N1b, N2b);
     const double u = kEps32;
-    // |s_c - s|: piece expansion 2 u Sb, and every MFMA of the chain adds at most 32 u (its own terms + what it is handed):
-    // the four MFMAs hold the terms of (x2 x1, x2 y1), (y2 x1, y2 y1), (x2, y2) and (x1, y1, 1) in this order, so the first
-    // group's magnitude is counted four times and the last one's once (2^-5: the lower-order piece products and the rounding of what is handed on)
-    const double es = (2.0 * Sb + 32.0 * (1.0 + 0x1.0p-5) * (4.0 * xm * xm * (A[0] + A[1]) + 3.0 * xm * xm * (A[3] + A[4]) + 2.0 * xm * (A[2] + A[5]) +
-                                                              (xm * (A[6] + A[7]) + A[8]))) * u;
+    // |s_c - s|: five of the nine piece products of every monomial are kept (1.1 * 2^-18 Sb), and every MFMA of the chain adds at
+    // most 32 u (its own terms + what it is handed): the three MFMAs hold the terms of (x2 x1, x2 y1, y2 x1), (y2 y1, x2, y2) and
+    // (x1, y1, 1) in this order, so the first group's magnitude is counted three times and the last one's once (2^-5: the
+    // lower-order piece products and the rounding of what is handed on)
+    const double es = (1.1 * 0x1.0p-18 / u * Sb + 32.0 * (1.0 + 0x1.0p-5) * (3.0 * xm * xm * (A[0] + A[1] + A[3]) + 2.0 * (xm * xm * A[4] + xm * (A[2] + A[5])) +
+                                                                            (xm * (A[6] + A[7]) + A[8]))) * u;
     // n1 and n2 are one MFMA each: kept piece products 3.1 * 2^-18, accumulation 34 u, and the x y monomial with two of
     // three products (2^-9 of its term, |x y| <= xm^2)
     const double q1ab = 2.0 * fabs(fma(e[0], e[1], e[3] * e[4])), q2ab = 2.0 * fabs(fma(e[0], e[3], e[1] * e[4]));
@@ -1175,19 +1176,18 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     ea_own = round_up_f32(cA * infl);
     eb_own = round_up_f32((cB + 1.001 * cC * k / 2.0 + 6.01 * infl * es * es) * infl);
     n2_offset = 2.0 * eS;
-    // round 1: the four vectors of s
-    pack_pieces(e[0], e[1], 0.0, true, bstage[lane][0][0], bstage[lane][0][1]);
-    pack_pieces(e[3], e[4], 0.0, true, bstage[lane][1][0], bstage[lane][1][1]);
-    pack_pieces(e[2], e[5], 0.0, true, bstage[lane][2][0], bstage[lane][2][1]);
-    pack_pieces(e[6], e[7], e[8], true, bstage[lane][3][0], bstage[lane][3][1]);
-    fetch_round(BE, 0, 4);
+    // round 1: the three vectors of s
+    pack_quad(e[0], e[1], e[3], true, bstage[lane][0][0], bstage[lane][0][1]);
+    pack_quad(e[4], e[2], e[5], true, bstage[lane][1][0], bstage[lane][1][1]);
+    pack_quad(e[6], e[7], e[8], true, bstage[lane][2][0], bstage[lane][2][1]);
+    fetch_round(BE, 0, 3);
     // round 2: the quadratic forms k n1 and n2, one vector each
     pack_form(k * fma(e[0], e[0], e[3] * e[3]), 2.0 * k * fma(e[0], e[1], e[3] * e[4]), k * fma(e[1], e[1], e[4] * e[4]),
               2.0 * k * fma(e[0], e[2], e[3] * e[5]), 2.0 * k * fma(e[1], e[2], e[4] * e[5]), k * fma(e[2], e[2], e[5] * e[5]), true, bstage[lane][0][0],
               bstage[lane][0][1]);
     pack_form(fma(e[0], e[0], e[1] * e[1]), 2.0 * fma(e[0], e[3], e[1] * e[4]), fma(e[3], e[3], e[4] * e[4]), 2.0 * fma(e[0], e[6], e[1] * e[7]),
               2.0 * fma(e[3], e[6], e[4] * e[7]), fma(e[6], e[6], e[7] * e[7]) + n2_offset, true, bstage[lane][1][0], bstage[lane][1][1]);
-    fetch_round(BE, 4, 2);
+    fetch_round(BE, 3, 2);
   }
   if constexpr (kDoH) {
     double A[9];
@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   if constexpr (kPark) {
     if constexpr (kDoE) {
 #pragma unroll
-      for (int v = 0; v < kParkedE; ++v) parked[64 * v + lane] = __builtin_bit_cast(uint4, BE[1][kDoE ? 6 - kParkedE + v : 0]);
+      for (int v = 0; v < kParkedE; ++v) parked[64 * v + lane] = __builtin_bit_cast(uint4, BE[1][kDoE ? 5 - kParkedE + v : 0]);
     } else {
 #pragma unroll
       for (int v = 0; v < 3; ++v) parked[64 * v + lane] = __builtin_bit_cast(uint4, BH[1][kDoH ? v : 0]);
@@ -1295,15 +1295,15 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   SFM_STAMP_BEGIN();
   // The match-side vectors of a tile are loaded one tile ahead: after the last MFMA of a tile has been issued their
   // registers are free, and the loads of the next tile then run under the vector work of the second hypothesis group.
-  bf16x8 A1, ASa, ASb, AN1, AN2, A2;
+  bf16x8 A1, AS1, AS2, AS3, AN1, AN2;
   auto load_tile = [&](const uint4* q) {
-    A1 = as_bf16x8(q[4 * 64]);
+    if constexpr (kDoH) A1 = as_bf16x8(q[4 * 64]);
     if constexpr (kDoE) {
-      ASa = as_bf16x8(q[0]);
-      ASb = as_bf16x8(q[64]);
+      AS1 = as_bf16x8(q[0]);
+      AS2 = as_bf16x8(q[64]);
       AN1 = as_bf16x8(q[2 * 64]);
       AN2 = as_bf16x8(q[3 * 64]);
-      A2 = as_bf16x8(q[5 * 64]);
+      AS3 = as_bf16x8(q[5 * 64]);
     }
   };
   if (t0 < t1) load_tile(src);
@@ -1325,7 +1325,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     for (int k = 0; k < 2; ++k) {
       unsigned amb_e = 0, amb_h = 0;
       if constexpr (kDoE) {
-        bf16x8 bn[2] = {BE[k][4], BE[k][5]};
+        bf16x8 bn[2] = {BE[k][3], BE[k][4]};
         if constexpr (kPark && kParkedE > 0) {
           if (k == 1) {
             int at = lane;
@@ -1334,12 +1334,11 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
             for (int v = 0; v < kParkedE; ++v) bn[2 - kParkedE + v] = as_bf16x8(parked[64 * v + at]);
           }
         }
-        f32x16 sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ASa, BE[k][0], zero, 0, 0, 0);
+        f32x16 sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS1, BE[k][0], zero, 0, 0, 0);
         const f32x16 n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AN1, bn[0], zero, 0, 0, 0);
-        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ASb, BE[k][1], sv, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS2, BE[k][1], sv, 0, 0, 0);
         const f32x16 n2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AN2, bn[1], zero, 0, 0, 0);
-        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, BE[k][2], sv, 0, 0, 0);
-        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, BE[k][3], sv, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS3, BE[k][2], sv, 0, 0, 0);
         if constexpr (!kDoH) {
           if (k == 1) load_tile(src);
         }
