@@ -1004,22 +1004,26 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma_kernel(const
 // The same exact counts with the WHOLE epipolar test on the matrix cores' outputs.  The float64 test of eh_score_kernel is
 //     s^2 (n1 + n2) < k n1 n2,   s = x2^T E x1,  n1 = |(E x1)_{0,1}|^2,  n2 = |(E^T x2)_{0,1}|^2,  k = 2 thr^2,
 // and s is a bilinear form in (x1, x2), n1 and n2 are quadratic forms in x1 and in x2: all three are contractions of
-// match-side monomials with hypothesis-side coefficients, so they come out of chained bf16 MFMAs
-//     s   = [x2 x1, x2 y1] . [E00, E01] + [y2 x1, y2 y1] . [E10, E11] + [x2, y2, 1] . [E02, E12, 0] + [x1, y1, 1] . [E20, E21, E22]
-//     n1' = k n1 = [x1^2, x1 y1, y1^2] . k [Qaa, Qab, Qbb] + [x1, y1, 1] . k [Qa, Qb, Q1]          (Q = coefficients of |(E x1)_{0,1}|^2)
-//     n2  =        [x2^2, x2 y2, y2^2] . [...]            + [x2, y2, 1] . [...]
-// (4 + 2 + 2 MFMAs per 32 x 32 pairs; monomials and coefficients are formed in float64 and split into three bf16 pieces;
-// the products of the quadratic monomials keep 5 of the 9 piece products, relative error 2^-17, which is ample: the norms
-// enter the test scaled by k).  The vector ALU is left with
-//     D = s^2 (n1'/k + n2) - n1' n2      (4 instructions; < 0 <=> inlier)      and the band      |D| <= S (A |s| + B) + C s^2 + T
-// (3 instructions + half a v_min3), 10 issue slots per pair with the sign history instead of 18.
+// match-side monomials with hypothesis-side coefficients (both formed in float64 and split into bf16 pieces), so they come
+// out of bf16 MFMAs, five per 32 x 32 pairs (every MFMA costs the SIMD about as much issue time as ten vector instructions):
+//     s   = [x2 x1, x2 y1, y2 x1] . [E00, E01, E10] + [y2 y1, x2, y2] . [E11, E02, E12] + [x1, y1, 1] . [E20, E21, E22]
+//           three chained MFMAs, five of the nine piece products per monomial (pack_quad: relative error 1.1 * 2^-18)
+//     n1' = k n1 = [x1^2, y1^2, x1, y1, x1 y1, 1] . k [Qaa, Qbb, Qa, Qb, Qab, Q1]       (Q = coefficients of |(E x1)_{0,1}|^2)
+//     n2  =        [x2^2, y2^2, x2, y2, x2 y2, 1] . [...]
+//           one MFMA each (pack_form: three piece products per monomial, two for x y and for the constant); the norms enter
+//           the test scaled by k, so 2^-16 of their value and 2^-9 of the x y term are ample.
+// The vector ALU is left with
+//     S = n1'/k + n2,  P = n1' n2,  D = s^2 S - P      (4 instructions; D < 0 <=> inlier)
+//     r = |D| - S (A |s| + B)                          (2 instructions; r < 0 <=> the sign of D is not trusted)
+// and one v_alignbit for each of the two signs: 10 issue slots per pair.
 // Error bound (everything relative to the float64 value of D on the unrounded inputs; u = 2^-24):
-//   |s_c - s| <= es = (2 + 32*4) u Sb   (piece expansion + accumulation of a 4-MFMA chain in any order, Sb >= sum |E||x2||x1|),
-//   |n_c - n| <= en = (2^-17 + 66 u) Nb (Nb >= sum |Q||monomial|), eS = en1 + en2,
-//   |s_c^2 S_c - s^2 S| <= s_c^2 eS + (2 |s_c| es + es^2)(S_c + eS),   |P_c - k n1 n2| <= k (S_c + eS) en + k en^2,
-//   float32 evaluation of D: 4.1 u s_c^2 S_c + u P_c <= 4.1 u Sb |s_c| S_c + u k Lb2 S_c,  Lb2 >= min(n1, n2),
-// collected (with 2 |s_c| es eS <= (s_c^2 + es^2) eS) as A = 2 es + 4.1 u (Sb + es), B = 3 es^2 + k en + u k Lb2, C = 2 eS,
-// T = the products of three error terms + an absolute floor, all doubled (safety) and rounded up.
+//   |s_c - s| <= es: piece products + 32 u per MFMA of the chain on (its own terms + what it is handed), Sb >= sum |E||x2||x1|;
+//   |n_c - n| <= en, eS = en1 + en2; n2's constant carries an offset 2 eS, so that S <= S_c - eS and S_c >= eS;
+//   |s_c^2 S_c - s^2 S| <= 3 eS s_c^2 + (2 |s_c| es + es^2) S_c + rounding,   |P_c - k n1 n2| <= 3 k eS S_c (1 + ...) + rounding,
+//   float32 evaluation of D: 3.1 u |s_c| (Sb + es) S_c + u k (Lb2 + 4 eS) S_c,  Lb2 >= min(n1, n2),
+// collected as |D_c - D| <= S_c (A |s_c| + B) + C s_c^2 with A = 2 es + 3.1 u (Sb + es), B = es^2 + 6 k eS + u k (Lb2 + 4 eS),
+// C = 3 eS; the C term is bounded by a multiple of S_c for every pair whose sign can be wrong and rides in B (see below);
+// A and B are doubled (safety) and rounded up.
 // ---------------------------------------------------------------------------------------
 constexpr int kEhxVecA = 6;  // match-side vectors per match: S1, S2 (six of the nine monomials of s), N1, N2 (the monomials of n1, n2), A1 = (x1, y1, 1) for the H test, S3 = (x1, y1, 1) in the five-product layout
 
