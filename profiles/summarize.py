@@ -136,7 +136,7 @@ def main(d, json_out=None):
         try:
             per = {}
             for name, st, en in c.execute("select name, start, end from kernels order by start"):
-                if any(k in name for k in ("eh_score_mfma", "eh_upper_mfma", "t_score_mfma", "corr_to_mfma", "t_prep_mfma")):
+                if any(k in name for k in ("eh_score_mfma", "eh_upper_mfma", "t_score_mfma", "corr_to_mfma", "corr_to_upper2", "t_prep_mfma")):
                     per.setdefault(name[:100], []).append((en - st) / 1e3)
             total = {}
             for name, durs in per.items():

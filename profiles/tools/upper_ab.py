@@ -31,3 +31,6 @@ print("floatcount", os.environ.get("SFM_HIP_EH_FLOATCOUNT"), "violations", int((
       "mean slack", float((ue[:S] - ce).float().mean()), float((uh[:S] - ch).float().mean()), "checksum", int(ue.sum()), int(uh.sum()))
 for r in range(3):
     print(f"round {r}: bound kernel {timeit(f):.3f} ms")
+for part in (1, 2):
+    g = lambda: ops.eh_upper_mfma(corr, corrm, idx, thr, 3 * thr, 0.0, out=(ue, uh), part=part)
+    print(f"part {part} alone (1 = epipolar, 2 = transfer): {timeit(g):.3f} ms")

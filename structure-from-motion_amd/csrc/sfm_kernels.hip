@@ -1095,6 +1095,320 @@ __global__ __launch_bounds__(kBlock) void corr_to_mfma3_kernel(const double4* __
   publish_absmax(c, j < n, reinterpret_cast<unsigned*>(xy + npad));  // 16-byte trailer, zeroed by the launcher
 }
 
+// ---------------------------------------------------------------------------------------
+// Matrix-core pre-filter, SECOND FORM (the one in use; eh_upper_mfma_kernel stays reachable with SFM_HIP_UPPER_FORM=0):
+// the one-sided epipolar test whole from the matrix cores.  s = x2^T E x1 is a bilinear form and k1 n1 = k1 |(E x1)_{0,1}|^2
+// a quadratic form in x1, i.e. contractions of match-side monomials with hypothesis-side coefficients, exactly as in
+// eh_score_mfma2_kernel: three chained MFMAs give s (vectors S1, S2, S3: five of the nine piece products per monomial) and
+// one gives N = k1 n1 + c (vector N1: the whole quadratic form, the slack constant c riding in its constant term), so the
+// test s^2 < N costs ONE vector instruction per pair (plus the count) instead of five after the rows E x1.
+// Upper-bound property.  A float64 inlier has s^2 (n1 + n2) < k n1 n2, hence s^2 < k n1.  With |s_c - s| <= es
+// (bound of eh_score_mfma2_kernel, same vectors, same chain order) and AM-GM, s_c^2 <= (1 + mu) s^2 + (1 + 1/mu) es^2
+// < k1 n1 + (1 + 1/mu) es^2 with k1 >= k (1 + mu), for any mu > 0 (chosen per hypothesis); the computed N_c errs by at most k1 en1 + kn c (piece products of the
+// form, the x y monomial at 2^-9, accumulation: en1 and kn as in eh_score_mfma2_kernel), so with
+//     c = ((1 + 1/mu) (f es)^2 + f k1 en1) / (1 - f kn)        (f = the caller's safety factor)
+// every float64 inlier has s_c^2 < N_c, and the fma N_c - s_c^2 has the sign of the exact difference.
+// kFloatCount (as in eh_upper_mfma_kernel): the outcome is clamp(N_c - s_c^2), exactly 0 or 1 when the hypothesis is
+// scaled by a power of two lambda with lambda^2 (1 + 1/mu) (f es)^2 >= 2^50: N_c' >= 2^50 is then a multiple of 2^27, an
+// s_c' whose square can cancel against it is at least 2^24.9 and so a multiple of 2, and the exact difference is an
+// integer: zero, negative, or at least 1.  lambda^2 beyond 2^116 could overflow a coefficient: such a hypothesis (all
+// coordinates below about 2^-12) reports the trivial bound.
+// The transfer half is the box test of eh_upper_mfma_kernel, unchanged.
+// Match-side operands: those of eh_upper_mfma_kernel (piece vector of (x1, y1, 1), (x2, y2) / sqrt(k1), trailer) followed by
+// evec[tile][S1, S2, S3, N1][match of the tile][half]: 168 bytes per match.
+// ---------------------------------------------------------------------------------------
+constexpr int kUp2Vec = 4;
+
+__global__ __launch_bounds__(kBlock) void corr_to_upper2_kernel(const double4* __restrict__ corr, int n, int npad, double inv_sqrt_k1,
+                                                                uint4* __restrict__ pieces, float2* __restrict__ xy, uint4* __restrict__ evec) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) *reinterpret_cast<double*>(xy + npad) = inv_sqrt_k1;  // tag: which threshold these operands were prepared for
+  double4 c = make_double4(0.0, 0.0, 0.0, 0.0);
+  if (j < npad) {
+    uint4* out = evec + ((long long)(j >> 5) * (kUp2Vec * 32) + (j & 31)) * 2;  // vector v at out[64 v], out[64 v + 1]
+    if (j < n) {
+      c = corr[j];
+      pack_pieces(c.x, c.y, 1.0, false, pieces[2 * j], pieces[2 * j + 1]);
+      xy[j] = make_float2((float)(c.z * inv_sqrt_k1), (float)(c.w * inv_sqrt_k1));
+      pack_quad(c.z * c.x, c.z * c.y, c.w * c.x, false, out[0], out[1]);
+      pack_quad(c.w * c.y, c.z, c.w, false, out[64], out[65]);
+      pack_quad(c.x, c.y, 1.0, false, out[128], out[129]);
+      pack_form(c.x * c.x, c.x * c.y, c.y * c.y, c.x, c.y, 1.0, false, out[192], out[193]);
+    } else {
+      pieces[2 * j] = pieces[2 * j + 1] = make_uint4(0, 0, 0, 0);
+      xy[j] = make_float2(0.0f, 0.0f);
+#pragma unroll
+      for (int v = 0; v < kUp2Vec; ++v) out[64 * v] = out[64 * v + 1] = make_uint4(0, 0, 0, 0);
+    }
+  }
+  publish_absmax(c, j < n, reinterpret_cast<unsigned*>(xy + npad) + 2);  // behind the tag; zeroed by the launcher
+}
+
+template <bool kDoE, bool kDoH, bool kFloatCount>
+__global__ __launch_bounds__(kBlock, 3) void eh_upper_mfma2_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
+                                                                   const float2* __restrict__ xy, const uint4* __restrict__ evec, int n,
+                                                                   const int32_t* __restrict__ idx, long long nb, double two_thr_e2,
+                                                                   double thr_h2, double xmax, double safety, int* __restrict__ up_e,
+                                                                   int* __restrict__ up_h, int tiles_per_split, int use_atomics) {
+  __shared__ unsigned char fin[kBlock / 64][64];
+  __shared__ uint4 bstage[kBlock / 64][64][4][2];  // four piece vectors per round
+  SFM_STAMP_ENTRY();
+  __builtin_amdgcn_s_setprio(3);  // the solve runs ahead of the other waves' tile loops (see eh_upper_mfma_kernel)
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long hyp = gid < nb ? gid : nb - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const double inv_sqrt_k1 = 1.0 / sqrt(uniform_k1(two_thr_e2));  // the scale of (x2, y2) in the operands of the box test
+  const int npad_all = ((n + 31) / 32) * 32;
+  const double xm = usable_xmax(xmax, reinterpret_cast<const unsigned*>(xy + npad_all)[2]);
+  constexpr bool kPark = kDoE && kDoH;
+  bf16x8 BE[2][kDoE ? 4 : 1], BH[2][kDoH ? 3 : 1];
+  {
+    double Ed[9], Hd[9], A[9];
+    float unused[9];
+    {
+      double p8[8][4], p4[4][4];
+      gather_samples<double>(corr, n, idx + 12 * hyp, p8, p4);
+      if constexpr (kDoE) solve_E8<double>(p8, Ed);
+      if constexpr (kDoH) solve_H4<double>(p4, Hd);
+    }
+    // bit 0 / 1: the E / H model is finite (a model with a non-finite entry has the float64 count 0); bit 2: the E bound of
+    // this hypothesis is the trivial one
+    unsigned flags = 0;
+    {
+      double chk_e = 0.0, chk_h = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        if constexpr (kDoE) chk_e = fma(Ed[i], 0.0, chk_e);  // NaN as soon as one entry is NaN or infinite
+        if constexpr (kDoH) chk_h = fma(Hd[i], 0.0, chk_h);
+      }
+      flags = (chk_e == 0.0 ? 1u : 0u) | (chk_h == 0.0 ? 2u : 0u);
+    }
+    if constexpr (kDoE) {
+      double e[9];
+      const double inv = to_unit_f32(Ed, unused, A);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) e[i] = Ed[i] * inv;
+      const double R0 = xm * (A[0] + A[1]) + A[2], R1 = xm * (A[3] + A[4]) + A[5], R2 = xm * (A[6] + A[7]) + A[8];
+      const double Sb = xm * (R0 + R1) + R2, N1b = R0 * R0 + R1 * R1;
+      const double u = kEps32;
+      const double es = (1.1 * 0x1.0p-18 / u * Sb + 32.0 * (1.0 + 0x1.0p-5) * (3.0 * xm * xm * (A[0] + A[1] + A[3]) + 2.0 * (xm * xm * A[4] + xm * (A[2] + A[5])) +
+                                                                              (xm * (A[6] + A[7]) + A[8]))) * u;
+      const double q1ab = 2.0 * fabs(fma(e[0], e[1], e[3] * e[4]));
+      const double kn = 3.1 * 0x1.0p-18 + 34.0 * u;
+      const double en1 = (kn * N1b + 0x1.02p-9 * xm * xm * q1ab) * 1.0001;
+      // Any mu > 0 is valid; the widening of the squared threshold, mu + (1 + 1/mu) (f es)^2 / (k n1), is smallest at
+      // mu = f es / sqrt(k n1): taken at the mean of n1 over coordinates spread evenly in [-xm, xm]
+      const double n1_ref = A[2] * A[2] + A[5] * A[5] + xm * xm / 3.0 * (A[0] * A[0] + A[1] * A[1] + A[3] * A[3] + A[4] * A[4]);
+      const double mu = fmin(0.5, fmax(0x1.0p-7, safety * es / sqrt(two_thr_e2 * n1_ref)));  // NaN (n1_ref = 0) -> 2^-7
+      const double k1 = two_thr_e2 * (1.0 + mu) * (1.0 + 32.0 * kEps32);
+      const double floor_c = (1.0 + 1.0 / mu) * (safety * es) * (safety * es);
+      const double cst = (floor_c + safety * k1 * en1) / (1.0 - safety * kn) * 1.0001;
+      double lam = 1.0;
+      if constexpr (kFloatCount) {
+        int ex = 0;
+        (void)frexp(floor_c, &ex);  // floor_c >= 2^(ex - 1)
+        int lg = (52 - ex) / 2;     // ceil((51 - ex) / 2) for every sign of 51 - ex that can occur with the guard below
+        if (2 * lg < 51 - ex) ++lg;
+        if (!(floor_c > 0.0) || lg > 58 || lg < -30) {
+          flags |= 4u;
+          lg = 0;
+        }
+        lam = ldexp(1.0, lg);
+      }
+      const double l2 = lam * lam * k1;
+      pack_quad(e[0] * lam, e[1] * lam, e[3] * lam, true, bstage[wave][lane][0][0], bstage[wave][lane][0][1]);
+      pack_quad(e[4] * lam, e[2] * lam, e[5] * lam, true, bstage[wave][lane][1][0], bstage[wave][lane][1][1]);
+      pack_quad(e[6] * lam, e[7] * lam, e[8] * lam, true, bstage[wave][lane][2][0], bstage[wave][lane][2][1]);
+      pack_form(l2 * fma(e[0], e[0], e[3] * e[3]), 2.0 * l2 * fma(e[0], e[1], e[3] * e[4]), l2 * fma(e[1], e[1], e[4] * e[4]),
+                2.0 * l2 * fma(e[0], e[2], e[3] * e[5]), 2.0 * l2 * fma(e[1], e[2], e[4] * e[5]),
+                l2 * fma(e[2], e[2], e[5] * e[5]) + lam * lam * cst, true, bstage[wave][lane][3][0], bstage[wave][lane][3][1]);
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) BE[k][v] = as_bf16x8(bstage[wave][32 * k + col][v][half]);
+      __syncthreads();
+    }
+    if constexpr (kDoH) {
+      double inv = to_unit_f32(Hd, unused, A);
+      const double R0 = xm * (A[0] + A[1]) + A[2], R1 = xm * (A[3] + A[4]) + A[5], R2 = xm * (A[6] + A[7]) + A[8];
+      const double ez = kEpsMfma * R2;
+      const double Dx = (kEpsMfma + 3.0 * kEps32) * (R0 + xm * R2), Dy = (kEpsMfma + 3.0 * kEps32) * (R1 + xm * R2);
+      const double G = safety * (sqrt(thr_h2) * ez + Dx + Dy);
+      inv *= kGh / G;
+      if constexpr (kFloatCount) inv *= kLambdaH;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        const double sc = v == 2 ? inv : inv * inv_sqrt_k1;
+        pack_pieces(Hd[3 * v] * sc, Hd[3 * v + 1] * sc, Hd[3 * v + 2] * sc, true, bstage[wave][lane][v][0], bstage[wave][lane][v][1]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) BH[k][v] = as_bf16x8(bstage[wave][32 * k + col][v][half]);
+      if constexpr (kPark) {
+        // the fused instantiation is a dozen registers short at three waves per SIMD: four of the six transfer-side piece
+        // vectors wait in LDS (one 16-byte read each per tile, consecutive lanes at consecutive addresses) instead of
+        // being spilled to scratch memory by the compiler
+        __syncthreads();
+        uint4* parked = &bstage[wave][0][0][0];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) parked[64 * v + lane] = __builtin_bit_cast(uint4, BH[1][v]);
+        parked[192 + lane] = __builtin_bit_cast(uint4, BH[0][2]);
+        __syncthreads();
+      }
+    }
+    fin[wave][lane] = (unsigned char)flags;  // parked in LDS: no register lives across the loop
+  }
+  const uint4* parked = &bstage[wave][0][0][0];
+  const float rtp = round_up_f32(sqrt(thr_h2) * inv_sqrt_k1 * (1.0 + 16.0 * kEps32));
+  const float gp = round_up_f32(kGh * inv_sqrt_k1 * (1.0 + 16.0 * kEps32)) * (kFloatCount ? (float)kLambdaH : 1.0f);
+  const int apos = 16 * ((col >> 2) & 1) + (col & 3) + 4 * (col >> 3);  // see eh_upper_mfma_kernel
+  const int ntiles = (n + 31) / 32;
+  const int t0 = blockIdx.y * tiles_per_split;
+  const int t1 = min(ntiles, t0 + tiles_per_split);
+  int ce[2] = {0, 0}, ch[2] = {0, 0};
+  unsigned he[2] = {0, 0}, hh[2] = {0, 0};
+  float fe[2] = {0.0f, 0.0f}, fh[2] = {0.0f, 0.0f};
+  const f32x16 zero = {0};
+  const unsigned tail_mask = tile_tail_mask(n, half);
+  const uint4* asrc = pieces + 2 * (t0 * 32 + apos) + half;
+  const float4* xsrc = reinterpret_cast<const float4*>(xy + t0 * 32 + 16 * half);
+  const uint4* esrc = evec + ((long long)t0 * (kUp2Vec * 32) + apos) * 2 + half;
+  // every match-side operand is loaded one tile ahead, into the registers its last reader has just released
+  bf16x8 A, AS1, AS2, AS3, AN1;
+  float x2[kDoH ? 16 : 1], y2[kDoH ? 16 : 1];
+  auto load_e = [&](const uint4* q) {
+    AS1 = as_bf16x8(q[0]);
+    AS2 = as_bf16x8(q[64]);
+    AS3 = as_bf16x8(q[128]);
+    AN1 = as_bf16x8(q[192]);
+  };
+  auto load_xy = [&](const float4* q, int pair) {
+    const float4 v = q[pair];
+    x2[2 * pair] = v.x; y2[2 * pair] = v.y; x2[2 * pair + 1] = v.z; y2[2 * pair + 1] = v.w;
+  };
+  if constexpr (kDoE) load_e(esrc);
+  if constexpr (kDoH) {
+    A = as_bf16x8(*asrc);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) load_xy(xsrc, i);
+  }
+  auto score_tile = [&](auto masked_tag, const uint4* anext, const float4* xnext, const uint4* enext) {
+    constexpr bool kMasked = decltype(masked_tag)::value;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if constexpr (kDoE) {
+        f32x16 sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS1, BE[k][0], zero, 0, 0, 0);
+        const f32x16 nv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AN1, BE[k][3], zero, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS2, BE[k][1], sv, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS3, BE[k][2], sv, 0, 0, 0);
+        if (k == 1) load_e(enext);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if constexpr (kFloatCount) {
+            // (the clamp is left to the compiler here: it must see the first reader of the matrix-core results to place
+            // the wait states that those need; behind an asm statement it does not)
+            const float t = __builtin_amdgcn_fmed3f(fma(-sv[i], sv[i], nv[i]), 0.0f, 1.0f);  // 1 <=> inlier (or within the slack)
+            if constexpr (kMasked)
+              fe[k] = fma(t, ((tail_mask >> (15 - i)) & 1u) ? 1.0f : 0.0f, fe[k]);
+            else
+              fe[k] += t;
+          } else {
+            const float d = fma(sv[i], sv[i], -nv[i]);  // inlier (or within the slack) <=> d < 0
+            he[k] = __builtin_amdgcn_alignbit(he[k], __float_as_uint(d), 31);
+          }
+        }
+        if constexpr (!kFloatCount) ce[k] += __popc(he[k] & (kMasked ? tail_mask : 0xFFFFu));
+      }
+      if constexpr (kDoH) {
+        bf16x8 h0 = BH[k][0], h1 = BH[k][1], h2 = BH[k][2];
+        if constexpr (kPark) {
+          int at = lane;
+          asm volatile("" : "+v"(at));  // keeps the reads inside the loop (hoisted, they would be spilled again)
+          if (k == 1) {
+            h0 = as_bf16x8(parked[at]);
+            h1 = as_bf16x8(parked[64 + at]);
+            h2 = as_bf16x8(parked[128 + at]);
+          } else {
+            h2 = as_bf16x8(parked[192 + at]);
+          }
+        }
+        const f32x16 hx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, h0, zero, 0, 0, 0);
+        const f32x16 hy = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, h1, zero, 0, 0, 0);
+        const f32x16 hz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, h2, zero, 0, 0, 0);
+        if (k == 1) A = as_bf16x8(*anext);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float dx = fma(x2[i], hz[i], -hx[i]);
+          const float dy = fma(y2[i], hz[i], -hy[i]);
+          if (k == 1 && (i & 1)) load_xy(xnext, i >> 1);
+          const float lim = fma(rtp, fabsf(hz[i]), gp);
+          if constexpr (kFloatCount) {
+            const float tx = clamp01_b_minus_abs(lim, dx), ty = clamp01_b_minus_abs(lim, dy);  // both 1 <=> inside the box
+            if constexpr (kMasked)
+              fh[k] = fma(tx * ty, ((tail_mask >> (15 - i)) & 1u) ? 1.0f : 0.0f, fh[k]);
+            else
+              fh[k] = fma(tx, ty, fh[k]);
+          } else {
+            const float d = fmaxf(fabsf(dx), fabsf(dy)) - lim;
+            hh[k] = __builtin_amdgcn_alignbit(hh[k], __float_as_uint(d), 31);
+          }
+        }
+        if constexpr (!kFloatCount) ch[k] += __popc(hh[k] & (kMasked ? tail_mask : 0xFFFFu));
+      }
+    }
+  };
+  __builtin_amdgcn_s_setprio(0);
+  SFM_STAMP_BEGIN();
+  const int t_partial = (n & 31) ? (n >> 5) : ntiles;  // the tile with padding, if any
+  const int t_full = min(t1, t_partial);
+  for (int t = t0; t < t_full; ++t) {
+    const bool more = t + 1 < t1;  // the last tile of the range loads itself again (in bounds, unused)
+    const uint4* anext = more ? asrc + 64 : asrc;
+    const float4* xnext = more ? xsrc + 16 : xsrc;
+    const uint4* enext = more ? esrc + kUp2Vec * 64 : esrc;
+    score_tile(std::false_type{}, anext, xnext, enext);
+    asrc = anext;
+    xsrc = xnext;
+    esrc = enext;
+  }
+  if (t_partial >= t0 && t_partial < t1) score_tile(std::true_type{}, asrc, xsrc, esrc);
+  if constexpr (kFloatCount) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      ce[k] = (int)fe[k];
+      ch[k] = (int)fh[k];
+    }
+  }
+  SFM_STAMP_END(t1 - t0);
+  int se[2], sh[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    se[k] = ce[k] + __shfl_xor(ce[k], 32);
+    sh[k] = ch[k] + __shfl_xor(ch[k], 32);
+  }
+  const unsigned ok = fin[wave][lane];
+  const int trivial = max(0, min(n, t1 * 32) - t0 * 32);  // all matches of this split
+  int oute = (ok & 1u) ? ((ok & 4u) ? trivial : (half ? se[1] : se[0])) : 0, outh = (ok & 2u) ? (half ? sh[1] : sh[0]) : 0;
+  // operands prepared for another threshold, or matches without a usable coordinate bound, cannot give valid bounds
+  if (*reinterpret_cast<const double*>(xy + npad_all) != inv_sqrt_k1 || !(xm < 1.0e6)) oute = outh = trivial;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // the hypothesis id is formed again here rather than held in two registers across the tile loop
+  const long long out_id = (long long)blockIdx.x * blockDim.x + tid;
+  if (out_id < nb) {
+    if (use_atomics) {
+      if constexpr (kDoE) atomicAdd(up_e + out_id, oute);
+      if constexpr (kDoH) atomicAdd(up_h + out_id, outh);
+    } else {
+      if constexpr (kDoE) up_e[out_id] = oute;
+      if constexpr (kDoH) up_h[out_id] = outh;
+    }
+  }
+}
+
 template <bool kDoE, bool kDoH, int kMinBlocks>
 __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
                                                                             const float2* __restrict__ xy, int n,
@@ -2760,17 +3074,19 @@ int sfm_eh_upper_f32(const double* corr, const float* corr32, int32_t n, const i
   return launch_eh_upper(corr, corr32, n, idx, nb, thr_e, thr_h, xmax, safety, one_sided, up_e, up_h, (hipStream_t)stream);
 }
 
-// match-side operands of the matrix-core pre-filter: [npad][32 B] piece vectors, then [npad] float2
+// match-side operands of the matrix-core pre-filter: [npad][32 B] piece vectors, [npad] float2, a 16-byte trailer, then
+// the four 32-byte vectors per match of the epipolar forms (tile-major, see corr_to_upper2_kernel)
 static inline int padded32(int n) { return (n + 31) & ~31; }
 
-int64_t sfm_corr_mfma_bytes(int32_t n) { return n <= 0 ? 0 : (int64_t)padded32(n) * 40 + 16; }
+int64_t sfm_corr_mfma_bytes(int32_t n) { return n <= 0 ? 0 : (int64_t)padded32(n) * (40 + kUp2Vec * 32) + 16; }
 
 static int launch_corr_to_mfma(const double* corr, int32_t n, double thr_e, void* corrm, hipStream_t st) {
   if (!corr || !corrm || n <= 0 || !(thr_e > 0.0) || ((uintptr_t)corrm & 15u) != 0) return SFM_EINVAL;
   const int npad = padded32(n);
   SFM_TRY(hipMemsetAsync((char*)corrm + (size_t)npad * 40, 0, 16, st));  // trailer: threshold tag + measured max |coordinate|
-  corr_to_mfma_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, 1.0 / sqrt(uniform_k1(2.0 * thr_e * thr_e)),
-                                                               (uint4*)corrm, (float2*)((char*)corrm + (size_t)npad * 32));
+  corr_to_upper2_kernel<<<div_up(npad, kBlock), kBlock, 0, st>>>((const double4*)corr, n, npad, 1.0 / sqrt(uniform_k1(2.0 * thr_e * thr_e)),
+                                                                 (uint4*)corrm, (float2*)((char*)corrm + (size_t)npad * 32),
+                                                                 (uint4*)((char*)corrm + (size_t)npad * 40 + 16));
   return check_launch();
 }
 
@@ -2797,27 +3113,39 @@ static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n
   if (splits > ntiles) splits = ntiles;
   const uint4* pieces = (const uint4*)corrm;
   const float2* xy = (const float2*)((const char*)corrm + (size_t)npad * 32);
+  const uint4* evec = (const uint4*)((const char*)corrm + (size_t)npad * 40 + 16);
+  // SFM_HIP_UPPER_FORM=0: the epipolar test from the rows E x1 on the vector ALU (eh_upper_mfma_kernel) instead of s and
+  // k1 n1 + c whole from the matrix cores (eh_upper_mfma2_kernel)
+  static const bool form2 = !(getenv("SFM_HIP_UPPER_FORM") && atoi(getenv("SFM_HIP_UPPER_FORM")) == 0);
   const double ke = 2.0 * thr_e * thr_e, kh = thr_h * thr_h;
   // clamped float counts (see eh_upper_mfma_kernel) for thresholds inside the range their exactness argument covers
   static const bool float_env = !(getenv("SFM_HIP_EH_FLOATCOUNT") && atoi(getenv("SFM_HIP_EH_FLOATCOUNT")) == 0);
   const double k1 = uniform_k1(ke);
   const bool float_count = float_env && k1 > 0x1.0p-45 && k1 < 0.6 && kh > 0x1.0p-45 && kh < 1.0e6;
-  // one launch over the hypothesis tiles [t_lo, t_hi) with the match range cut into `sp` pieces
-  auto launch = [&](long long t_lo, long long t_hi, int sp) -> int {
+  // one launch over the hypothesis tiles [t_lo, t_hi) with the match range cut into `sp` pieces; which = 0: both tests in
+  // one launch, 1 / 2: the epipolar / the transfer test alone (second form: that launch solves and writes its own model only)
+  auto launch = [&](long long t_lo, long long t_hi, int sp, int which) -> int {
     const long long off = t_lo * kBlock;
     const long long cnt = (t_hi * kBlock < nb ? t_hi * kBlock : nb) - off;
     const int tps = div_up(ntiles, sp);
+    const bool own_only = form2 && which != 0;
     if (sp > 1) {
-      SFM_TRY(hipMemsetAsync(up_e + off, 0, sizeof(int32_t) * cnt, st));
-      SFM_TRY(hipMemsetAsync(up_h + off, 0, sizeof(int32_t) * cnt, st));
+      if (!(own_only && which == 2)) SFM_TRY(hipMemsetAsync(up_e + off, 0, sizeof(int32_t) * cnt, st));
+      if (!(own_only && which == 1)) SFM_TRY(hipMemsetAsync(up_h + off, 0, sizeof(int32_t) * cnt, st));
     }
     const dim3 grid((unsigned)(t_hi - t_lo), sp);
-#define SFM_LAUNCH_UPPER(E_, H_, F_)                                                                                                   \
-  eh_upper_mfma_kernel<E_, H_, F_><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, ke, kh, xmax, safety, \
-                                                            up_e + off, up_h + off, tps, sp > 1)
-    if (part == 1) {  // measurement only: the epipolar half alone (up_h receives zeros)
+#define SFM_LAUNCH_UPPER(E_, H_, F_)                                                                                                          \
+  do {                                                                                                                                        \
+    if (form2)                                                                                                                                \
+      eh_upper_mfma2_kernel<E_, H_, F_><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, evec, n, idx + 12 * off, cnt, ke, kh, xmax,  \
+                                                                 safety, up_e + off, up_h + off, tps, sp > 1);                                \
+    else                                                                                                                                      \
+      eh_upper_mfma_kernel<E_, H_, F_><<<grid, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, ke, kh, xmax, safety, \
+                                                                up_e + off, up_h + off, tps, sp > 1);                                         \
+  } while (0)
+    if (which == 1) {
       if (float_count) SFM_LAUNCH_UPPER(true, false, true); else SFM_LAUNCH_UPPER(true, false, false);
-    } else if (part == 2) {  // measurement only: the transfer half alone
+    } else if (which == 2) {
       if (float_count) SFM_LAUNCH_UPPER(false, true, true); else SFM_LAUNCH_UPPER(false, true, false);
     } else {
       if (float_count) SFM_LAUNCH_UPPER(true, true, true); else SFM_LAUNCH_UPPER(true, true, false);
@@ -2830,23 +3158,36 @@ static int launch_eh_upper_mfma(const double* corr, const void* corrm, int32_t n
   // launched apart with their match range cut into pieces: as many workgroups as a full round, each a fraction of the work
   // (2-3 % for one call at a time; a caller that keeps several blocks in flight on several streams fills the last round
   // with the next block's work anyway and is better off without the extra launch: cut_last_round = false).
-  static const long long slots = [] {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0LL;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0LL;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, eh_upper_mfma_kernel<true, true, true>, kBlock, 0) != hipSuccess) return 0LL;
-    return (long long)cus * per_cu;
-  }();
+  static const long long slots_both = form2 ? chip_slots(eh_upper_mfma2_kernel<true, true, true>) : chip_slots(eh_upper_mfma_kernel<true, true, true>);
+  static const long long slots_e = form2 ? chip_slots(eh_upper_mfma2_kernel<true, false, true>) : chip_slots(eh_upper_mfma_kernel<true, false, true>);
+  static const long long slots_h = form2 ? chip_slots(eh_upper_mfma2_kernel<false, true, true>) : chip_slots(eh_upper_mfma_kernel<false, true, true>);
   static const bool cut_tail = !(getenv("SFM_HIP_EH_TAIL") && atoi(getenv("SFM_HIP_EH_TAIL")) == 0);
-  const long long rem = slots > 0 ? tiles % slots : 0;
-  if (cut_tail && cut_last_round && splits == 1 && tiles > slots && rem > 0 && rem * 4 <= slots) {
-    int sp = (int)(slots / rem);
-    if (sp > 16) sp = 16;  // every piece solves its hypotheses again: keep that below the work it saves
-    if (sp > ntiles) sp = ntiles;
-    SFM_TRY(launch(0, tiles - rem, 1));
-    return launch(tiles - rem, tiles, sp);
+  auto launch_all = [&](int which) -> int {
+    const long long slots = which == 1 ? slots_e : which == 2 ? slots_h : slots_both;
+    const long long rem = slots > 0 ? tiles % slots : 0;
+    if (cut_tail && cut_last_round && splits == 1 && tiles > slots && rem > 0 && rem * 4 <= slots) {
+      int sp = (int)(slots / rem);
+      if (sp > 16) sp = 16;  // every piece solves its hypotheses again: keep that below the work it saves
+      if (sp > ntiles) sp = ntiles;
+      SFM_TRY(launch(0, tiles - rem, 1, which));
+      return launch(tiles - rem, tiles, sp, which);
+    }
+    return launch(0, tiles, splits, which);
+  };
+  if (part != 0) {  // measurement only: one test alone; the other array receives zeros
+    SFM_TRY(hipMemsetAsync(part == 1 ? up_h : up_e, 0, sizeof(int32_t) * nb, st));
+    return launch_all(part);
   }
-  return launch(0, tiles, splits);
+  // Second form: one launch per test from 2^28 pairs on.  Each then fits four waves per SIMD (the fused instantiation: three,
+  // with four piece vectors waiting in LDS), solves only its own model and reads the index rows once more; below that size
+  // the second launch costs more than it gains.
+  static const int split_env = getenv("SFM_HIP_UPPER_SPLIT") ? atoi(getenv("SFM_HIP_UPPER_SPLIT")) : -1;
+  const bool split_tests = form2 && (split_env >= 0 ? split_env != 0 : (long long)nb * n >= (1LL << 28));
+  if (split_tests) {
+    SFM_TRY(launch_all(1));
+    return launch_all(2);
+  }
+  return launch_all(0);
 }
 
 int sfm_eh_upper_mfma_f32(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h,
@@ -3051,7 +3392,7 @@ inline size_t carve(char* base, int64_t nb, int32_t n, BestWs* w) {
   w->rows = (int32_t*)take(sizeof(int32_t) * 12 * 2 * kCandCap);
   w->sc_e = (int*)take(sizeof(int) * 2 * kCandCap);
   w->sc_h = (int*)take(sizeof(int) * 2 * kCandCap);
-  w->corrm = take((size_t)((n + 31) & ~31) * 40 + 16);
+  w->corrm = take((size_t)sfm_corr_mfma_bytes(n));
   w->spec_ids = (int32_t*)take(sizeof(int32_t) * 2 * kSpecCap);
   w->pending = (BestPending*)take(sizeof(BestPending));
   return off;

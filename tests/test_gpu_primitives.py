@@ -303,7 +303,7 @@ def test_native_cascade_entry_point(ops, dev, inl, pl, n, B, seed, loose):
         (cE, iE), (cH, iH), stats = ops.eh_best_native(corr, c32, idx, thr, 3 * thr, xmax, loose=loose, workspace=ws)
         assert (cE, iE) == (int(ce.max()), int(np.argmax(ce))), stats
         assert (cH, iH) == (int(ch.max()), int(np.argmax(ch))), stats
-    if inl == 0.0:
+    if (inl, loose) in ((0.0, 1), (0.05, 2)):  # the scenes on which the first level of that kind leaves thousands of candidates
         assert stats["tightened"] > 4096  # the middle level really ran
 
 
@@ -322,7 +322,7 @@ def test_native_cascade_universal_ties_fall_back_to_float64(ops, dev):
 def test_native_cascade_many_loose_survivors(ops, dev):
     """A scene whose best counts are tiny: more hypotheses survive the loose bounds than the
     candidate lists hold, so the tight bounds are applied to everything before the float64 level."""
-    n, B = 3000, 400000
+    n, B = 3000, 600000
     sc, x1, x2 = scene(n=n, inl=0.0, pl=0.5, seed=8)
     corr_h = ops.pack_corr(x1, x2)
     corr = dev(corr_h)
@@ -356,8 +356,9 @@ def test_device_index_sets_match_oracle_and_are_sharding_invariant(ops):
 
 @pytest.mark.parametrize("n,B,inl,seed", [(1500, 20000, 0.5, 1), (10000, 50000, 0.3, 0), (97, 4099, 0.8, 2), (32, 64, 0.9, 3), (5000, 3000, 0.0, 4)])
 def test_matrix_core_bounds_are_upper_bounds(ops, dev, n, B, inl, seed):
-    """sfm_eh_upper_mfma_f32 (E x1 and H x1 on the bf16 matrix cores from three-piece splits): never below the exact
-    float64 count, and about as tight as the vector-ALU form of the same tests."""
+    """sfm_eh_upper_mfma_f32 (s = x2' E x1, k n1 and H x1 on the bf16 matrix cores from three-piece splits): never below
+    the exact float64 count; the transfer bound about as tight as the vector-ALU form of the same test, the epipolar bound
+    (whose s carries the error of three chained matrix instructions) within a few counts of it."""
     sc, x1, x2 = scene(n=n, inl=inl, pl=0.5, seed=seed)
     corr_h = ops.pack_corr(x1, x2)
     corr = dev(corr_h)
@@ -368,7 +369,7 @@ def test_matrix_core_bounds_are_upper_bounds(ops, dev, n, B, inl, seed):
     me, mh = ops.eh_upper_mfma(corr, ops.corr_to_mfma(corr, thr), idx, thr, 3 * thr, xmax)
     ve, vh = ops.eh_upper(corr, ops.corr_to_f32(corr), idx, thr, 3 * thr, xmax, one_sided=True)
     assert int((me < ce).sum()) == 0 and int((mh < ch).sum()) == 0
-    assert float((me - ce).double().mean()) <= float((ve - ce).double().mean()) * 1.2 + 0.5
+    assert float((me - ce).double().mean()) <= float((ve - ce).double().mean()) * 3.5 + 1.0
     assert float((mh - ch).double().mean()) <= float((vh - ch).double().mean()) * 1.2 + 0.5
 
 

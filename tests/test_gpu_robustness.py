@@ -94,6 +94,38 @@ def test_unusable_coordinates_fall_back_to_trivial_bounds_and_float64(env):
         assert wE == (int(ce_h.max()), int(np.argmax(ce_h))) and wH == (int(ch_h.max()), int(np.argmax(ch_h)))
 
 
+def test_matrix_core_bounds_across_coordinate_scales_and_thresholds(env):
+    """The matrix-core bounds (epipolar test whole from the matrix cores, counted through the output clamp of a
+    power-of-two scaled test value) stay upper bounds of the float64 counts in pixel coordinates, in tiny and in large
+    coordinate scales and from a hundredth of a pixel to tens of pixels, and the cascade on top of them names the float64
+    winner."""
+    torch, C, ops = env
+    n, B = 2000, 30000
+    sc, x1, x2 = scene(n, inl=0.4, seed=21)
+    f = sc["K"][0][0]
+    idx = C.dev(np.random.default_rng(5).integers(0, n, (B, 12)), np.int32)
+    cases = [("pixels", None, 1.0), ("pixels, 0.01 px", None, 0.01), ("pixels, 40 px", None, 40.0)]
+    cases += [("scale %g" % sc_, sc_, 1.0) for sc_ in (1.0e-3, 2.0 ** -9, 2.0 ** -15, 30.0, 900.0)]
+    for name, scale, px in cases:
+        if scale is None:
+            a, b, thr = np.array(sc["x1"], float), np.array(sc["x2"], float), px
+        else:
+            a, b, thr = x1.copy(), x2.copy(), px / f * scale
+            a[:2] *= scale
+            b[:2] *= scale
+        corr_h = ops.pack_corr(a, b)
+        corr = C.dev(corr_h)
+        ce, ch = ops.eh_score(corr, idx, thr, 3 * thr)
+        ue, uh = ops.eh_upper_mfma(corr, ops.corr_to_mfma(corr, thr), idx, thr, 3 * thr, 0.0)
+        assert int((ue < ce).sum()) == 0 and int((uh < ch).sum()) == 0, name
+        slack = float((ue - ce).double().mean())
+        if scale is None or scale > 1.0e-4:
+            assert slack < 0.25 * n, (name, slack)  # a real bound, not the trivial one
+        wE, wH, _ = ops.eh_best_native(corr, ops.corr_to_f32(corr), idx, thr, 3 * thr, 0.0, loose=2)
+        ce_h, ch_h = ce.cpu().numpy(), ch.cpu().numpy()
+        assert wE == (int(ce_h.max()), int(np.argmax(ce_h))) and wH == (int(ch_h.max()), int(np.argmax(ch_h))), name
+
+
 def test_non_positive_thresholds_follow_the_reference(env):
     """thr_h <= 0 and the reprojection threshold <= 0 admit nothing (the reference compares a norm with them); a
     negative epipolar threshold behaves like its absolute value (the reference squares it)."""
