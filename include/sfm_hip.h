@@ -248,16 +248,18 @@ int sfm_lm_translation_f64(const double* K, const double* pts, const int64_t* ca
 int sfm_index_sets_i32(uint64_t seed, uint64_t first_id, int64_t nb, int32_t n, int32_t width, int32_t* idx, void* stream);
 
 /* Matrix-core form of the loose float32 bounds (same meaning and guarantees as sfm_eh_upper_f32 with
- * one_sided = 1: up >= exact count for every hypothesis).  The 3x3 products E x1 and H x1 of
- * src/ransac_algorithm.py:206-207 and :320 run on the bf16 matrix cores from three-piece bf16 splits
- * of the float64 models and coordinates; the rest of the two tests stays on the vector ALU.
+ * one_sided = 1: up >= exact count for every hypothesis).  The epipolar residual x2' E x1 and the squared line norm
+ * |(E x1)_{0,1}|^2 of src/ransac_algorithm.py:206-212 (a bilinear and a quadratic form) and the product H x1 of :320 run
+ * on the bf16 matrix cores from three-piece bf16 splits of the float64 models and coordinates; the comparisons and the
+ * counts stay on the vector ALU.
  * corrm: match-side operands written by sfm_corr_to_mfma FOR THE SAME thr_e (the second view's coordinates are stored
- * divided by the square root of the slackened threshold constant); sfm_corr_mfma_bytes(n) bytes, 16-byte aligned. */
+ * divided by the square root of the slackened threshold constant); sfm_corr_mfma_bytes(n) bytes (168 per match, rounded
+ * up to 32 matches, + 16), 16-byte aligned. */
 int64_t sfm_corr_mfma_bytes(int32_t n);
 int sfm_corr_to_mfma(const double* corr, int32_t n, double thr_e, void* corrm, void* stream);
 int sfm_eh_upper_mfma_f32(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e,
                           double thr_h, double xmax, double safety, int32_t* up_e, int32_t* up_h, void* stream);
-/* Measurement aid: the same launch with only the epipolar test (part = 1: the inner loop of
+/* Measurement aid: only the launch of the epipolar test (part = 1: the inner loop of
  * src/ransac_algorithm.py:98-102) or only the transfer test (part = 2: :120-121); the other output is zero. */
 int sfm_eh_upper_mfma_part_f32(const double* corr, const void* corrm, int32_t n, const int32_t* idx, int64_t nb, double thr_e,
                                double thr_h, double xmax, double safety, int32_t part, int32_t* up_e, int32_t* up_h,
