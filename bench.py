@@ -241,8 +241,11 @@ class ExactScorer:
     the two packed winners.  Blocks are submitted to `depth` slots in turn (own stream, count arrays, workspace and
     page-locked result words per slot), so `depth` blocks can be in flight; collect(slot) waits for that slot's block."""
 
-    def __init__(self, torch, _capi, ops, corr, thr, xmax, max_block, n, depth):
+    def __init__(self, torch, _capi, ops, corr, thr, xmax, max_block, n, depth, full_test=True):
         self.torch, self.ops = torch, ops
+        # full_test: every pair through the full symmetric-epipolar and disc tests (the unit of `value`); False: the library's
+        # default, in which a pair that fails a cheaper implied test is counted out without the full test (same counts)
+        self.full_test = full_test
         self.corr, self.thr, self.xmax = corr, thr, xmax
         lib = _capi.load_library()
         self.depth = depth
@@ -260,7 +263,8 @@ class ExactScorer:
         with self.torch.cuda.stream(self.streams[slot]):
             ce, ch = self.ce[slot][:nb], self.ch[slot][:nb]
             self.best[slot].zero_()
-            self.ops.eh_score_mixed(self.corr, idx, self.thr, 3 * self.thr, self.xmax, out=(ce, ch), workspace=self.ws[slot])
+            self.ops.eh_score_mixed(self.corr, idx, self.thr, 3 * self.thr, self.xmax, out=(ce, ch), workspace=self.ws[slot],
+                                    every_pair_full_test=self.full_test)
             self.ops.argmax_count(ce, first_id, self.best[slot][0:1])
             self.ops.argmax_count(ch, first_id, self.best[slot][1:2])
             self.host[slot].copy_(self.best[slot], non_blocking=True)
@@ -474,7 +478,8 @@ def seed_sweep(torch, ops, _capi, synthetic, orc, n, B):
 
 def sweep(torch, ops, _capi, synthetic, orc, seed):
     """Throughput over match-set sizes (one GPU, one step at a time): the exact step (every pair decided by the reference's
-    tests: sfm_eh_score_mixed + arg-max) and the bound-driven arg-max step (sfm_eh_best), which must name the same winners."""
+    tests: sfm_eh_score_mixed_opt without early loops + arg-max), the same exact counts with the library's early loops, and the
+    bound-driven arg-max step (sfm_eh_best); all three must name the same winners."""
     rows = []
     for n, B in [(2000, 1000000), (10000, 1000000), (50000, 400000), (200000, 100000), (200000, 12500000)]:
         sc = synthetic.two_view_scene(n=n, inlier_ratio=0.3, planar_ratio=0.5, seed=seed)
@@ -497,6 +502,14 @@ def sweep(torch, ops, _capi, synthetic, orc, seed):
         dte = (time.perf_counter() - t0) / reps
         cnt, ind = ops.decode_best(np.array(keys, dtype=np.int64))
         del scorer
+        scorer = ExactScorer(torch, _capi, ops, corr, thr, xmax, B, n, 1, full_test=False)  # the same counts with the early loops
+        scorer.run([(idx, 0)] * (1 if big else 3))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        keys_early = scorer.run([(idx, 0)] * reps)
+        torch.cuda.synchronize()
+        dtee = (time.perf_counter() - t0) / reps
+        del scorer
         ws = ops.eh_best_workspace(B, n)
         for _ in range(1 if big else 3):
             ops.eh_best_native(corr, corr32, idx, thr, 3 * thr, xmax, workspace=ws)
@@ -509,6 +522,8 @@ def sweep(torch, ops, _capi, synthetic, orc, seed):
         rows.append({"matches": n, "hypotheses": B,
                      "exact_ms_per_step": dte * 1e3, "exact_evals_per_s": 2.0 * n * B / dte, "exact_tflops_algorithmic": 57.0 * n * B / dte / 1e12,
                      "exact_frac_of_fp32_vector_peak": 57.0 * n * B / dte / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                     "exact_early_out_ms_per_step": dtee * 1e3, "exact_early_out_pairs_per_s": 2.0 * n * B / dtee,
+                     "exact_early_out_winners_equal": bool(list(keys_early) == list(keys)),
                      "bound_driven_ms_per_step": dt * 1e3, "bound_driven_bounded_pairs_per_s": 2.0 * n * B / dt,
                      "winner_E": [int(cnt[0]), int(ind[0])], "winner_H": [int(cnt[1]), int(ind[1])],
                      "bound_driven_winners_equal": bool(list(wE) == [int(cnt[0]), int(ind[0])] and list(wH) == [int(cnt[1]), int(ind[1])]), **st})
@@ -743,11 +758,11 @@ def run_c5(args, torch, dist, orc, _capi, ops, sharding, synthetic, world, rank,
     idx = [ops.index_sets(args.seed, a, b - a, n) for a, b in blocks]
     depth = 1 if args.no_overlap else 2
     bmax = max(b - a for a, b in blocks)
-    exact = args.c5_mode == "exact"
+    exact = args.c5_mode in ("exact", "early")
     best = torch.zeros(2, dtype=torch.int64, device=key_device)
     stats = {"candidates_e": 0, "candidates_h": 0, "tightened": 0, "rescored_f64": 0}
     if exact:
-        scorer = ExactScorer(torch, _capi, ops, corr, thr, 0.0, bmax, n, depth)
+        scorer = ExactScorer(torch, _capi, ops, corr, thr, 0.0, bmax, n, depth, full_test=args.c5_mode == "exact")
     else:
         streams = [torch.cuda.Stream() for _ in range(depth)]
         workspaces = [ops.eh_best_workspace(bmax, n) for _ in range(depth)]
@@ -809,8 +824,11 @@ def run_c5(args, torch, dist, orc, _capi, ops, sharding, synthetic, world, rank,
         return
     cnt, ind = ops.decode_best(best.cpu().numpy())
     value = 2.0 * n * total * args.steps / dt
-    how = ("every (hypothesis, match) pair decided by the reference's two residual tests (sfm_eh_score_mixed: the float64 inlier counts of every "
-           "hypothesis), arg-max of the counts" if exact else
+    full = args.c5_mode == "exact"
+    how = ("every (hypothesis, match) pair decided by the reference's two residual tests (sfm_eh_score_mixed_opt without early loops: the float64 "
+           "inlier counts of every hypothesis), arg-max of the counts" if full else
+           "the float64 inlier counts of every hypothesis with the library's early loops (sfm_eh_score_mixed: a pair that fails a cheaper implied "
+           "test skips the full test; pairs decided, not full residual evaluations), arg-max of the counts" if exact else
            "residual evaluations counted as bounded pairs: every (hypothesis, match) pair takes the matrix-core bound tests, candidates are re-scored "
            "in float64; exact winner = first maximum of the float64 inlier counts")
     out = {
@@ -840,9 +858,9 @@ def run_c5(args, torch, dist, orc, _capi, ops, sharding, synthetic, world, rank,
             "winner_H": {"count": int(cnt[1]), "index": int(ind[1])},
         },
         "roofline": {"bound": "valu_fp32", "kernel": "eh_score_mfma2_kernel" if exact else "eh_upper_mfma2_kernel",
-                     "achieved": (FLOPS_PER_E_EVAL + FLOPS_PER_H_EVAL) / 2.0 * value / world / 1e12 if exact else None,
+                     "achieved": (FLOPS_PER_E_EVAL + FLOPS_PER_H_EVAL) / 2.0 * value / world / 1e12 if full else None,
                      "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                     "frac": (FLOPS_PER_E_EVAL + FLOPS_PER_H_EVAL) / 2.0 * value / world / 1e12 / PEAK_FP32_VALU_TFLOPS if exact else None,
+                     "frac": (FLOPS_PER_E_EVAL + FLOPS_PER_H_EVAL) / 2.0 * value / world / 1e12 / PEAK_FP32_VALU_TFLOPS if full else None,
                      "traffic": None,
                      "note": "per GPU, from the whole-step rate (57 algorithmic flops per pair); the kernel's own event-timed duration, its counters "
                      "and the CPU baseline are those of the one-GPU default run (`python bench.py`): this line is the scaling measurement"},
@@ -860,8 +878,9 @@ def main():
     ap.add_argument("--workload", choices=["auto", "c2", "c5"], default="auto",
                     help="c2: 10 000 matches x 10^6 hypotheses per GPU (weak scaling); c5: 200 000 matches x 10^8 hypotheses in total, split over "
                     "the GPUs (strong scaling); auto = c2 on one GPU, c5 on several")
-    ap.add_argument("--c5-mode", choices=["exact", "bound"], default="exact",
-                    help="c5 only: exact = every pair decided by the reference's tests (the unit of `value`); bound = the bound-driven arg-max step")
+    ap.add_argument("--c5-mode", choices=["exact", "early", "bound"], default="exact",
+                    help="c5 only: exact = every pair decided by the reference's tests (the unit of `value`); early = the same exact counts with the "
+                    "library's early loops (pairs that fail a cheaper implied test skip the full test); bound = the bound-driven arg-max step")
     ap.add_argument("--matches", type=int, default=0, help="0 = the workload's own size")
     ap.add_argument("--hyps", type=int, default=0, help="c2: hypotheses per GPU; c5: hypotheses in total; 0 = the workload's own size")
     ap.add_argument("--cpu-sample", type=int, default=50000, help="hypotheses of the CPU baseline sample (0 = skip)")
@@ -1020,14 +1039,52 @@ def main():
     mixed_ws = torch.empty(int(_capi.load_library().sfm_eh_score_mixed_workspace_bytes(B, n)), dtype=torch.uint8, device="cuda")
     ce2 = torch.empty_like(ce)
     ch2 = torch.empty_like(ch)
-    ops.eh_score_mixed(corr, idx, thr, 3 * thr, xmax, out=(ce2, ch2), workspace=mixed_ws)
+    ops.eh_score_mixed(corr, idx, thr, 3 * thr, xmax, out=(ce2, ch2), workspace=mixed_ws, every_pair_full_test=True)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in ev:
         a.record()
-        ops.eh_score_mixed(corr, idx, thr, 3 * thr, xmax, out=(ce2, ch2), workspace=mixed_ws)
+        ops.eh_score_mixed(corr, idx, thr, 3 * thr, xmax, out=(ce2, ch2), workspace=mixed_ws, every_pair_full_test=True)
         b.record()
     torch.cuda.synchronize()
     mixed_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    # ---- the same exact counts with the library's early loops (not `value`): a pair that fails a cheaper implied test (one-sided
+    # epipolar distance; x part of the disc test) is proven to be no float64 inlier and skips the full test
+    ce3 = torch.empty_like(ce)
+    ch3 = torch.empty_like(ch)
+    ops.eh_score_mixed(corr, idx, thr, 3 * thr, xmax, out=(ce3, ch3), workspace=mixed_ws, every_pair_full_test=False)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:
+        a.record()
+        ops.eh_score_mixed(corr, idx, thr, 3 * thr, xmax, out=(ce3, ch3), workspace=mixed_ws, every_pair_full_test=False)
+        b.record()
+    torch.cuda.synchronize()
+    early_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    early_identical = bool(torch.equal(ce3, ce2) and torch.equal(ch3, ch2))
+    del ce3, ch3
+    early_scorer = ExactScorer(torch, _capi, ops, corr, thr, xmax, B, n, depth, full_test=False)
+    early_best = torch.zeros(2, dtype=torch.int64, device=key_device)
+
+    def run_early_steps(k, d):
+        pending = []
+        for i in range(k):
+            if len(pending) == d:
+                early_best.copy_(torch.tensor(early_scorer.collect(pending.pop(0)), dtype=torch.int64))
+                sharding.merge_best(early_best)
+            early_scorer.submit(i % d, idx, base)
+            pending.append(i % d)
+        while pending:
+            early_best.copy_(torch.tensor(early_scorer.collect(pending.pop(0)), dtype=torch.int64))
+            sharding.merge_best(early_best)
+
+    run_early_steps(args.warmup, depth)
+    sync()
+    t1 = time.perf_counter()
+    run_early_steps(args.steps, depth)
+    sync()
+    early_dt = time.perf_counter() - t1
+    early_winner = ops.decode_best(early_best.cpu().numpy())
+    del early_scorer
 
     # ---- the bound-driven arg-max step (not `value`): matrix-core bounds for every pair -> candidates -> float64 re-score
     # -> the same exact winners; two steps in flight as above
@@ -1202,9 +1259,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"synthetic two-view E+H RANSAC: {n} matches, 30% inliers, {B} hypotheses per GPU (8-pt E + 4-pt H solved per "
-                "hypothesis; every (hypothesis, match) pair decided by the reference's symmetric-epipolar and transfer tests: sfm_eh_score_mixed "
-                "gives the float64 inlier counts of every hypothesis; then sfm_argmax_count_i32 on both count arrays), winners merged by "
-                "all-reduce(max)",
+                "hypothesis; every (hypothesis, match) pair decided by the reference's symmetric-epipolar and transfer tests: sfm_eh_score_mixed_opt "
+                "with SFM_EHX_EVERY_PAIR_FULL_TEST, i.e. without the library's early loops, gives the float64 inlier counts of every hypothesis; "
+                "then sfm_argmax_count_i32 on both count arrays), winners merged by all-reduce(max)",
                 "matches": n,
                 "hypotheses_per_gpu": B,
                 "index_sets": "np.random.randint on the host (legacy stream)" if index_source == "legacy"
@@ -1217,6 +1274,21 @@ def main():
             "effective_value": evals_per_step * args.steps / eff_dt,
             "effective_ms_per_step": eff_dt / args.steps * 1e3,
             "effective": effective,
+            "exact_counts_early_out_value": evals_per_step * args.steps / early_dt,
+            "exact_counts_early_out_ms_per_step": early_dt / args.steps * 1e3,
+            "exact_counts_early_out": {
+                "what": "the library's default form of the exact step (sfm_eh_score_mixed + sfm_argmax_count_i32, what estimate_E_robust's block "
+                "scoring calls): the float64 inlier counts of EVERY hypothesis, identical to the headline step's, but a pair that fails a cheaper "
+                "implied test -- the one-sided epipolar test s^2 < k1 n1 + c (4 matrix + 3 vector issue slots per pair instead of 5 + 10), the x "
+                "part (dx - q)(dx + q) < g of the disc test (2 + 5 instead of 3 + 8) -- is proven to be no float64 inlier and skips the full "
+                "test; the few pairs per thousand that pass take the float64 test.  Pairs decided per second, NOT `value`: most pairs do not go "
+                "through the reference's full residual arithmetic, so its algorithmic rate may exceed the vector peak",
+                "kernel_ms": early_ms,
+                "counts_identical_to_headline_step": early_identical,
+                "winners_equal_headline_step": bool(int(early_winner[0][0]) == int(cnt[0]) and int(early_winner[1][0]) == int(ind[0])
+                                                    and int(early_winner[0][1]) == int(cnt[1]) and int(early_winner[1][1]) == int(ind[1])),
+                "algorithmic_tflops": flops_per_launch / (early_ms * 1e-3) / 1e12,
+            },
         }
         if no_overlap_ms is not None:
             out["no_overlap_ms_per_step"] = no_overlap_ms

@@ -111,10 +111,21 @@ int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_
  * bilinear form s = x2^T E x1, the squared line norms |(E x1)_{0,1}|^2, |(E^T x2)_{0,1}|^2 and the row H x1 come from MFMAs
  * of three-piece splits; a pair whose float32 test value lies inside the rigorous error band around the threshold is
  * re-evaluated with the float64 test inside the kernel (queued per wave, 64 pairs at a time).
+ * Early loops (default): each test is implied by a cheaper one -- the symmetric epipolar test of src/ransac_algorithm.py:98-102
+ * by its one-sided half (distance to the epipolar line in the second view alone, widened by the rigorous error band), the
+ * disc test of :120-121, :320-327 by its x component -- and a pair that fails the cheaper test is proven to be no float64
+ * inlier without the full test; the few pairs per thousand that pass take the float64 test.  A wave whose hypotheses come from
+ * all-inlier samples (most pairs pass) goes over to the full float32 tests.  The counts are the same either way.
+ * sfm_eh_score_mixed_opt: options = SFM_EHX_EVERY_PAIR_FULL_TEST sends EVERY pair through the full symmetric-epipolar and
+ * disc tests (no early loop; what bench.py's headline rate is measured on), 0 = sfm_eh_score_mixed.
  * xmax: hint, see Conventions.  workspace: sfm_eh_score_mixed_workspace_bytes(nb, n) bytes, 256-byte aligned. */
+#define SFM_EHX_EVERY_PAIR_FULL_TEST 1
 int64_t sfm_eh_score_mixed_workspace_bytes(int64_t nb, int32_t n);
 int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax,
                        void* workspace, int64_t workspace_bytes, int32_t* count_e, int32_t* count_h, void* stream);
+int sfm_eh_score_mixed_opt(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax,
+                           int32_t options, void* workspace, int64_t workspace_bytes, int32_t* count_e, int32_t* count_h,
+                           void* stream);
 
 /* sfm_eh_score_mixed for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc): same counts, no workspace argument, and no hipMalloc / hipFree or other

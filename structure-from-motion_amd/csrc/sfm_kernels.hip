@@ -1414,11 +1414,11 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
                                                                             const float2* __restrict__ xy, int n,
                                                                             const int32_t* __restrict__ idx, long long nb, double two_thr_e2,
                                                                             double thr_h2, double xmax, int* __restrict__ count_e,
-                                                                            int* __restrict__ count_h, int tiles_per_split, int use_atomics) {
+                                                                            int* __restrict__ count_h, int tiles_per_split, int use_atomics, int early) {
   constexpr int kModel = 9 * ((kDoE ? 1 : 0) + (kDoH ? 1 : 0));  // doubles per hypothesis parked for the float64 re-evaluation
   constexpr bool kPark = kDoE != kDoH;          // a one-model instantiation keeps some piece vectors in LDS, see below
   constexpr int kParkedE = 0;  // piece vectors of the second hypothesis group that the E-only instantiation keeps in LDS
-  constexpr int kParked = kPark ? (kDoE ? kParkedE : 4) : 0;
+  constexpr int kParked = kPark ? 4 : 0;  // H: four vectors re-read per tile; E: the four vectors of k n1 and n2 wait there while the early loop runs
   constexpr int kAfter = kModel * 8 * 64 + kParked * 16 * 64;  // the staging area later holds the float64 models and the parked vectors
   constexpr int kStageBytes = kAfter > 4 * 32 * 64 ? kAfter : 4 * 32 * 64;  // four piece vectors per round first
   constexpr int kQueue = 256;  // pairs whose float32 sign is not trusted wait here for a dense float64 pass (per wave)
@@ -1438,7 +1438,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   uint4(*bstage)[4][2] = reinterpret_cast<uint4(*)[4][2]>(&stage_raw[wave][0]);  // [lane][vector of the round][half]
   double Ed[9], Hd[9];
   float ea_own = 0.0f, eb_own = 0.0f, gh_own = 0.0f;
-  bf16x8 BE[2][kDoE ? 5 : 1], BH[2][kDoH ? 3 : 1];
+  bf16x8 BE[2][kDoE ? 6 : 1], BH[2][kDoH ? 3 : 1];  // BE[.][5]: the form of the early test
   {
     double p8[8][4], p4[4][4];
     gather_samples<double>(corr, n, idx + 12 * hyp, p8, p4);
@@ -1505,7 +1505,18 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
               bstage[lane][0][1]);
     pack_form(fma(e[0], e[0], e[1] * e[1]), 2.0 * fma(e[0], e[3], e[1] * e[4]), fma(e[3], e[3], e[4] * e[4]), 2.0 * fma(e[0], e[6], e[1] * e[7]),
               2.0 * fma(e[3], e[6], e[4] * e[7]), fma(e[6], e[6], e[7] * e[7]) + n2_offset, true, bstage[lane][1][0], bstage[lane][1][1]);
-    fetch_round(BE, 3, 2);
+    {
+      // the early test s^2 < k1 n1 + c of eh_upper_mfma2_kernel (safety factor 2): a pair that fails it is no float64 inlier
+      const double en1 = (kn * N1b + 0x1.02p-9 * xm * xm * q1ab) * 1.0001;
+      const double n1_ref = A[2] * A[2] + A[5] * A[5] + xm * xm / 3.0 * (A[0] * A[0] + A[1] * A[1] + A[3] * A[3] + A[4] * A[4]);
+      const double mu = fmin(0.5, fmax(0x1.0p-7, safety * es / sqrt(k * n1_ref)));
+      const double k1 = k * (1.0 + mu) * (1.0 + 32.0 * kEps32);
+      const double cst = ((1.0 + 1.0 / mu) * (safety * es) * (safety * es) + safety * k1 * en1) / (1.0 - safety * kn) * 1.0001;
+      pack_form(k1 * fma(e[0], e[0], e[3] * e[3]), 2.0 * k1 * fma(e[0], e[1], e[3] * e[4]), k1 * fma(e[1], e[1], e[4] * e[4]),
+                2.0 * k1 * fma(e[0], e[2], e[3] * e[5]), 2.0 * k1 * fma(e[1], e[2], e[4] * e[5]), k1 * fma(e[2], e[2], e[5] * e[5]) + cst, true,
+                bstage[lane][2][0], bstage[lane][2][1]);
+    }
+    fetch_round(BE, 3, 3);
   }
   if constexpr (kDoH) {
     double A[9];
@@ -1548,8 +1559,10 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   }
   if constexpr (kPark) {
     if constexpr (kDoE) {
+      if (early) {
 #pragma unroll
-      for (int v = 0; v < kParkedE; ++v) parked[64 * v + lane] = __builtin_bit_cast(uint4, BE[1][kDoE ? 5 - kParkedE + v : 0]);
+        for (int v = 0; v < 4; ++v) parked[64 * v + lane] = __builtin_bit_cast(uint4, BE[v >> 1][kDoE ? 3 + (v & 1) : 0]);
+      }
     } else {
 #pragma unroll
       for (int v = 0; v < 3; ++v) parked[64 * v + lane] = __builtin_bit_cast(uint4, BH[1][kDoH ? v : 0]);
@@ -1625,7 +1638,77 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     }
   };
   if (t0 < t1) load_tile(src);
-  for (int t = t0; t < t1; ++t, xsrc += 16) {
+  int t = t0;
+  // EARLY LOOP (one-model instantiations).  Each test is implied by a cheaper one whose failure proves a pair to be no float64
+  // inlier: the symmetric epipolar test by the one-sided s^2 < k1 n1 + c of eh_upper_mfma2_kernel (four MFMAs and three
+  // issue slots per pair instead of five and ten), the disc test dx^2 + dy^2 < q^2 by its x part (dx - q)(dx + q) < gh (two
+  // MFMAs and five slots instead of three and eight; gh >= 4 Q e + e^2 covers the computed product of a true inlier, whose
+  // |dx| is below |q| <= Q).  The pairs that pass (a few per thousand for most hypotheses) go straight to the float64 queue;
+  // nothing else is counted here.  A wave most of whose rows hold passing pairs (hypotheses from all-inlier samples) leaves
+  // this loop for the full float32 tests below: it reloads the tile it was on and goes on from there.
+  if (kPark && early) {
+    constexpr int kDenseRows = 40;  // of the 128 sixteen-pair rows of a wave and tile
+    for (; t < t1; ++t, xsrc += 16) {
+      unsigned fill = t == (n >> 5) ? 0u : 0xFFFFu;
+      asm volatile("" : "+s"(fill));
+      const unsigned vmask = tail_mask | fill;
+      const bool more = t + 1 < t1;
+      if (more) src += kEhxVecA * 64;
+      float x2[kDoH ? 16 : 1];
+      if constexpr (kDoH) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float4 v = xsrc[i];
+          x2[2 * i] = v.x; x2[2 * i + 1] = v.z;
+        }
+      }
+      unsigned pass[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        unsigned hp = 0;
+        if constexpr (kDoE) {
+          f32x16 sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS1, BE[k][0], zero, 0, 0, 0);
+          const f32x16 nv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AN1, BE[k][kDoE ? 5 : 0], zero, 0, 0, 0);
+          sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS2, BE[k][1], sv, 0, 0, 0);
+          sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS3, BE[k][2], sv, 0, 0, 0);
+          if (k == 1) load_tile(src);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) hp = __builtin_amdgcn_alignbit(hp, __float_as_uint(fma(sv[i], sv[i], -nv[i])), 31);  // < 0 <=> passes
+          pass[k] = (hp | force_f64) & vmask;
+        } else {
+          int at = lane;
+          asm volatile("" : "+v"(at));
+          const bf16x8 h0 = k == 1 ? as_bf16x8(parked[at]) : BH[k][0];
+          const bf16x8 h2 = as_bf16x8(parked[(k == 1 ? 128 : 192) + at]);
+          const f32x16 hx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, h0, zero, 0, 0, 0);
+          const f32x16 hz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, h2, zero, 0, 0, 0);
+          if (k == 1) load_tile(src);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float P = fma(x2[i], hz[i], -hx[i]);
+            const float M = fma(two_rt, hz[i], P);
+            hp = __builtin_amdgcn_alignbit(hp, __float_as_uint(fma(P, M, -gh[k])), 31);  // < 0 <=> passes
+          }
+          pass[k] = (hp | force_h) & vmask;
+        }
+      }
+      const unsigned long long any0 = ballot64(pass[0] != 0u), any1 = ballot64(pass[1] != 0u);
+      if (__popcll(any0) + __popcll(any1) > kDenseRows) {
+        if (more) src -= kEhxVecA * 64;
+        load_tile(src);  // this tile again (the next one was on its way)
+        break;
+      }
+      if (any0) enqueue(pass[0], any0, col, kDoE ? 0 : 1, t * 32 + 16 * half);
+      if (any1) enqueue(pass[1], any1, 32 + col, kDoE ? 0 : 1, t * 32 + 16 * half);
+    }
+    if constexpr (kDoE) {  // the vectors of k n1 and n2 come back for the full tests (unconditionally: they are dead inside the early loop)
+      int at = lane;
+      asm volatile("" : "+v"(at));
+#pragma unroll
+      for (int v = 0; v < 4; ++v) BE[v >> 1][kDoE ? 3 + (v & 1) : 0] = as_bf16x8(parked[64 * v + at]);
+    }
+  }
+  for (; t < t1; ++t, xsrc += 16) {
     // (a v_cndmask costs 18 issue cycles of the SIMD on this chip: the per-tile masks are formed with scalar selects and an OR)
     unsigned fill = t == (n >> 5) ? 0u : 0xFFFFu;
     asm volatile("" : "+s"(fill));  // keeps the select scalar
@@ -2981,7 +3064,7 @@ const char* sfm_hip_error_string(int code) {
   return hipGetErrorString((hipError_t)code);
 }
 
-int sfm_hip_abi_version(void) { return 3; }
+int sfm_hip_abi_version(void) { return 4; }
 
 #ifdef SFM_CLOCK_STAMPS
 // diagnostic build only: copies the first `slots` stamp records (8 x uint64 each)
@@ -3213,7 +3296,7 @@ int64_t sfm_eh_score_mixed_workspace_bytes(int64_t nb, int32_t n) {
 
 // workspace: sfm_eh_score_mixed_workspace_bytes(nb, n) bytes of device memory, 256-byte aligned (checked by the callers)
 static int run_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax,
-                              void* workspace, int32_t* count_e, int32_t* count_h, hipStream_t st) {
+                              void* workspace, int32_t* count_e, int32_t* count_h, hipStream_t st, int32_t options = 0) {
   if (!corr || !idx || !count_e || !count_h || !workspace || n <= 0 || nb < 0) return SFM_EINVAL;
   if (!(xmax >= 0.0 && xmax < 1.0e300)) return SFM_EINVAL;
   if (nb == 0) return 0;
@@ -3256,6 +3339,9 @@ static int run_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx,
     // always one launch per model (at 3 and 4 waves per SIMD; a fused instantiation would need 256 registers and spill)
     // As in launch_eh_upper_mfma: a last round of the grid that is less than a quarter full is launched apart with its
     // match range cut into pieces (the E launch holds 768 workgroups at a time: 3907 of them are 5.09 rounds).
+    // SFM_HIP_EHX_EARLY=0: every pair through the full float32 tests (no early loop)
+    static const int early_default = !(getenv("SFM_HIP_EHX_EARLY") && atoi(getenv("SFM_HIP_EHX_EARLY")) == 0);
+    const int early_env = (early_default && !(options & SFM_EHX_EVERY_PAIR_FULL_TEST)) ? 1 : 0;
     static const bool cut_tail = !(getenv("SFM_HIP_EHX_TAIL") && atoi(getenv("SFM_HIP_EHX_TAIL")) == 0);
     static const long long slots_e = chip_slots(eh_score_mfma2_kernel<true, false, 3>), slots_h = chip_slots(eh_score_mfma2_kernel<false, true, 4>);
     auto launch_model = [&](bool model_e, long long slots) -> int {
@@ -3268,10 +3354,10 @@ static int run_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx,
         const int tp = div_up(ntiles, sp);
         if (model_e)
           eh_score_mfma2_kernel<true, false, 3><<<g, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, 2.0 * thr_e * thr_e,
-                                                                     thr_h * thr_h, xmax, count_e + off, count_h + off, tp, sp > 1);
+                                                                     thr_h * thr_h, xmax, count_e + off, count_h + off, tp, sp > 1, early_env);
         else
           eh_score_mfma2_kernel<false, true, 4><<<g, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, 2.0 * thr_e * thr_e,
-                                                                     thr_h * thr_h, xmax, count_e + off, count_h + off, tp, sp > 1);
+                                                                     thr_h * thr_h, xmax, count_e + off, count_h + off, tp, sp > 1, early_env);
         return check_launch();
       };
       const long long rem = slots > 0 ? tiles % slots : 0;
@@ -3303,12 +3389,17 @@ static int run_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx,
   return check_launch();
 }
 
+int sfm_eh_score_mixed_opt(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax,
+                           int32_t options, void* workspace, int64_t workspace_bytes, int32_t* count_e, int32_t* count_h, void* stream) {
+  clear_stale_error();
+  if (!workspace || n <= 0 || nb < 0 || ((uintptr_t)workspace & 255u) != 0 || (options & ~SFM_EHX_EVERY_PAIR_FULL_TEST) != 0) return SFM_EINVAL;
+  if (workspace_bytes < sfm_eh_score_mixed_workspace_bytes(nb, n)) return SFM_EINVAL;
+  return run_eh_score_mixed(corr, n, idx, nb, thr_e, thr_h, xmax, workspace, count_e, count_h, (hipStream_t)stream, options);
+}
+
 int sfm_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx, int64_t nb, double thr_e, double thr_h, double xmax, void* workspace,
                        int64_t workspace_bytes, int32_t* count_e, int32_t* count_h, void* stream) {
-  clear_stale_error();
-  if (!workspace || n <= 0 || nb < 0 || ((uintptr_t)workspace & 255u) != 0) return SFM_EINVAL;
-  if (workspace_bytes < sfm_eh_score_mixed_workspace_bytes(nb, n)) return SFM_EINVAL;
-  return run_eh_score_mixed(corr, n, idx, nb, thr_e, thr_h, xmax, workspace, count_e, count_h, (hipStream_t)stream);
+  return sfm_eh_score_mixed_opt(corr, n, idx, nb, thr_e, thr_h, xmax, 0, workspace, workspace_bytes, count_e, count_h, stream);
 }
 
 // ---- the same scoring for callers that cannot allocate ---------------------------------------

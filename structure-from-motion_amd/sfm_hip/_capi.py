@@ -23,6 +23,8 @@ _SIGS = {
     "sfm_eh_score_f64": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _P, _P, _P]),
     "sfm_eh_score_mixed_workspace_bytes": (_c.c_int64, [_c.c_int64, _c.c_int32]),
     "sfm_eh_score_mixed": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _c.c_double, _P, _c.c_int64, _P, _P, _P]),
+    "sfm_eh_score_mixed_opt": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _c.c_double, _c.c_int32, _P, _c.c_int64, _P, _P,
+                               _P]),
     "sfm_eh_score_noalloc": (_c.c_int, [_P, _c.c_int32, _P, _c.c_int64, _c.c_double, _c.c_double, _P, _P, _P]),
     "sfm_corr_f32_bytes": (_c.c_int64, [_c.c_int32]),
     "sfm_corr_to_f32": (_c.c_int, [_P, _c.c_int32, _P, _P]),

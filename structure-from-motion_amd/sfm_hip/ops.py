@@ -52,10 +52,14 @@ def eh_score(corr, idx, thr_e, thr_h, out=None):
     return ce, ch
 
 
-def eh_score_mixed(corr, idx, thr_e, thr_h, xmax=0.0, out=None, workspace=None):
+EVERY_PAIR_FULL_TEST = False  # default of eh_score_mixed's every_pair_full_test (the tests run both forms through it)
+
+
+def eh_score_mixed(corr, idx, thr_e, thr_h, xmax=0.0, out=None, workspace=None, every_pair_full_test=None):
     """The counts of eh_score (identical for every hypothesis) with the residual tests on the matrix cores + float32 and a
     float64 re-evaluation of the pairs inside the error band.  xmax: optional hint of max |coordinate| over corr; the
-    library measures it on the device and uses the larger value."""
+    library measures it on the device and uses the larger value.  every_pair_full_test: no early loops (a pair that fails a
+    cheaper implied test is otherwise counted out without the full test); the counts are the same."""
     torch = C.torch_cuda()
     lib = C.load_library()
     nb, n = idx.shape[0], corr.shape[0]
@@ -66,8 +70,10 @@ def eh_score_mixed(corr, idx, thr_e, thr_h, xmax=0.0, out=None, workspace=None):
         ce, ch = out
     if workspace is None:
         workspace = _empty((max(256, int(lib.sfm_eh_score_mixed_workspace_bytes(nb, n))),), torch.uint8)
-    C.check(lib.sfm_eh_score_mixed(C.dptr(corr), n, C.dptr(idx), nb, float(thr_e), float(thr_h), float(xmax), C.dptr(workspace),
-                                   workspace.numel(), C.dptr(ce), C.dptr(ch), C.stream_ptr()))
+    if every_pair_full_test is None:
+        every_pair_full_test = EVERY_PAIR_FULL_TEST
+    C.check(lib.sfm_eh_score_mixed_opt(C.dptr(corr), n, C.dptr(idx), nb, float(thr_e), float(thr_h), float(xmax), 1 if every_pair_full_test else 0,
+                                       C.dptr(workspace), workspace.numel(), C.dptr(ce), C.dptr(ch), C.stream_ptr()))
     return ce, ch
 
 

@@ -25,6 +25,16 @@ def golden():
     return load
 
 
+@pytest.fixture(params=["early loops", "every pair through the full tests"])
+def mixed_form(request, monkeypatch):
+    """Runs a test once per form of the exact matrix-core scorer (ops.eh_score_mixed): with its early loops (pairs that fail a
+    cheaper implied test are counted out without the full test) and with every pair through the full float32 tests."""
+    from sfm_hip import ops
+
+    monkeypatch.setattr(ops, "EVERY_PAIR_FULL_TEST", request.param != "early loops")
+    return request.param
+
+
 def has_gpu():
     try:
         import torch

@@ -3,7 +3,8 @@
     python tests/stress_gpu.py [n_configs] > profiles/<tag>_stress.txt
 
 For random scenes (inlier ratio, planar share, match count, noise, threshold) it checks that
-  * sfm_eh_score_mixed returns the counts of sfm_eh_score_f64 for every hypothesis,
+  * sfm_eh_score_mixed (with its early loops and with every pair through the full tests) returns the counts of
+    sfm_eh_score_f64 for every hypothesis,
   * sfm_eh_best (all three first-level forms) returns the first maximum of those counts,
   * every float32 / matrix-core bound is an upper bound of the float64 count,
   * sfm_t_ransac_mixed returns the counts of sfm_t_ransac_f64 for every hypothesis.
@@ -47,8 +48,10 @@ def main(n_cfg, seed=2024):
         idx = ops.index_sets(c, 0, B, n)
         ce, ch = ops.eh_score(corr, idx, thr, 3 * thr)
         want = ((int(ce.max()), int((ce == ce.max()).nonzero()[0])), (int(ch.max()), int((ch == ch.max()).nonzero()[0])))
-        me, mh = ops.eh_score_mixed(corr, idx, thr, 3 * thr, xmax)
+        me, mh = ops.eh_score_mixed(corr, idx, thr, 3 * thr, xmax, every_pair_full_test=False)  # with the early loops
         viol = 0 if (torch.equal(me, ce) and torch.equal(mh, ch)) else 10**9  # the mixed-precision exact counts
+        me, mh = ops.eh_score_mixed(corr, idx, thr, 3 * thr, xmax, every_pair_full_test=True)
+        viol += 0 if (torch.equal(me, ce) and torch.equal(mh, ch)) else 10**9
         for name, (ue, uh) in [("tight", ops.eh_upper(corr, c32, idx, thr, 3 * thr, xmax, one_sided=False)),
                                ("loose", ops.eh_upper(corr, c32, idx, thr, 3 * thr, xmax, one_sided=True)),
                                ("mfma", ops.eh_upper_mfma(corr, cm, idx, thr, 3 * thr, xmax))]:

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_capi.EXPORTED_SYMBOLS) == names
-    assert lib.sfm_hip_abi_version() == 3
+    assert lib.sfm_hip_abi_version() == 4
     assert b"invalid" in lib.sfm_hip_error_string(100001)
 
 

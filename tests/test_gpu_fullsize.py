@@ -27,7 +27,7 @@ def env():
     return torch, _capi, ops
 
 
-def test_c2_full_size_properties(env):
+def test_c2_full_size_properties(env, mixed_form):
     torch, C, ops = env
     n, B = 10000, 1000000
     sc = synthetic.two_view_scene(n=n, inlier_ratio=0.3, planar_ratio=0.5, seed=2)

@@ -488,7 +488,7 @@ def test_mixed_translation_ransac_in_other_scales_and_thresholds(ops, dev, scale
 
 @pytest.mark.parametrize("n,B,inl,pl,px,seed", [(1500, 20000, 0.5, 0.5, 1.0, 1), (10000, 60000, 0.3, 0.5, 1.0, 0), (97, 4099, 0.8, 1.0, 0.5, 2),
                                                 (12, 64, 0.9, 0.0, 3.0, 3), (5000, 3000, 0.0, 0.5, 1.0, 4), (2048, 257, 0.95, 0.5, 1.0, 5)])
-def test_mixed_eh_scoring_counts_are_identical_to_float64(ops, dev, n, B, inl, pl, px, seed):
+def test_mixed_eh_scoring_counts_are_identical_to_float64(ops, dev, n, B, inl, pl, px, seed, mixed_form):
     """sfm_eh_score_mixed (matrix cores + float32, float64 inside the error bands) against sfm_eh_score_f64: every count."""
     import torch
 
@@ -502,7 +502,7 @@ def test_mixed_eh_scoring_counts_are_identical_to_float64(ops, dev, n, B, inl, p
     assert torch.equal(ce, me) and torch.equal(ch, mh)
 
 
-def test_mixed_eh_scoring_on_the_threshold_and_degenerate_inputs(ops, dev):
+def test_mixed_eh_scoring_on_the_threshold_and_degenerate_inputs(ops, dev, mixed_form):
     """Matches constructed to lie within 1e-7 (relative) of the transfer threshold of a known homography and of the
     epipolar threshold of a known essential matrix, duplicated sample indices, and a set of identical matches."""
     import torch
@@ -537,7 +537,7 @@ def test_mixed_eh_scoring_on_the_threshold_and_degenerate_inputs(ops, dev):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
-def test_mixed_eh_scoring_in_other_coordinate_scales_and_near_the_epipoles(ops, dev):
+def test_mixed_eh_scoring_in_other_coordinate_scales_and_near_the_epipoles(ops, dev, mixed_form):
     """The exact scorer takes s = x2^T E x1 and the squared line norms whole from the matrix cores and decides
     s^2 (n1 + n2) < k n1 n2 with a band derived from the coordinate bound: the counts must equal the float64 kernel's for
     pixel coordinates (|x| up to 2000, thresholds in pixels), for tiny coordinates, for matches piled up around both

@@ -25,7 +25,7 @@ def scene(n, inl=0.5, seed=7):
     return sc, orc.normalize_K(sc["K"], sc["x1"]), orc.normalize_K(sc["K"], sc["x2"])
 
 
-def test_understated_xmax_hint_still_gives_bounds_and_exact_winner(env):
+def test_understated_xmax_hint_still_gives_bounds_and_exact_winner(env, mixed_form):
     """The caller's xmax is a hint only: 1e-9 (absurdly small) and 0 (unknown) give the same bounds as the true
     maximum, because the library measures the maximum while it prepares the match-side operands."""
     torch, C, ops = env
@@ -67,7 +67,7 @@ def test_understated_xmax_hint_still_gives_bounds_and_exact_winner(env):
                                          C.stream_ptr()) == 100001
 
 
-def test_unusable_coordinates_fall_back_to_trivial_bounds_and_float64(env):
+def test_unusable_coordinates_fall_back_to_trivial_bounds_and_float64(env, mixed_form):
     """A NaN or huge coordinate leaves no usable bound: upper bounds become n, the exact mixed scorer evaluates every
     pair in float64 and still equals the float64 kernel, and the cascade still names the float64 winner."""
     torch, C, ops = env
@@ -203,7 +203,7 @@ def test_models_do_not_depend_on_wave_neighbours(env):
         assert np.array_equal(Ea[0], Ea[63], equal_nan=True)
 
 
-def test_large_but_finite_coordinates_keep_exact_counts(env):
+def test_large_but_finite_coordinates_keep_exact_counts(env, mixed_form):
     """Coordinates far outside the normalised range: pixel-sized values (float32 error bands grow with them), one match at
     3e5 (bounds still usable, the exact scorer already routes every pair to float64) and a translation problem whose
     points are so large that float32 squares would overflow.  Every mixed-precision count must equal the float64 count."""
