@@ -1585,7 +1585,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   // worked off 64 pairs at a time with the float64 tests of eh_score_kernel; the verdicts are added to per-hypothesis
   // counters in LDS.  entry = match << 7 | test << 6 | hypothesis of the wave.
   const unsigned force_f64 = all_f64 ? 0xFFFFu : 0u, force_h = !(xm < 1.0e5) ? 0xFFFFu : 0u;  // wave-uniform
-  int qlen = 0;
+  int qlen = 0, qtot = 0;  // qtot: pairs queued so far (wave-uniform)
   auto drain = [&]() {
     __builtin_amdgcn_wave_barrier();
     for (int base = 0; base < qlen; base += 64) {
@@ -1618,6 +1618,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
       const int pos = qlen + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(any >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)any, 0u));
       if (act) qbuf[wave][pos] = entry;
       qlen += __popcll(any);
+      qtot += __popcll(any);
       if (qlen > kQueue - 64) drain();
       any = ballot64(amb != 0u);
     } while (any);
@@ -1644,10 +1645,12 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   // issue slots per pair instead of five and ten), the disc test dx^2 + dy^2 < q^2 by its x part (dx - q)(dx + q) < gh (two
   // MFMAs and five slots instead of three and eight; gh >= 4 Q e + e^2 covers the computed product of a true inlier, whose
   // |dx| is below |q| <= Q).  The pairs that pass (a few per thousand for most hypotheses) go straight to the float64 queue;
-  // nothing else is counted here.  A wave most of whose rows hold passing pairs (hypotheses from all-inlier samples) leaves
-  // this loop for the full float32 tests below: it reloads the tile it was on and goes on from there.
+  // nothing else is counted here.  The queue costs about eight issue cycles per pair, the early loop saves 500 (E) / 250 (H)
+  // per tile of 2048 pairs: a wave with several hypotheses from all-inlier samples is better off with the full float32
+  // tests below.  It goes over to them for good when a tile has queued more than kDensePairs pairs, and at once (reloading
+  // the tile it is on) when more than kDenseRows of the tile's 128 sixteen-pair rows hold a passing pair.
   if (kPark && early) {
-    constexpr int kDenseRows = 40;  // of the 128 sixteen-pair rows of a wave and tile
+    constexpr int kDenseRows = 40, kDensePairs = kDoE ? 64 : 32;
     for (; t < t1; ++t, xsrc += 16) {
       unsigned fill = t == (n >> 5) ? 0u : 0xFFFFu;
       asm volatile("" : "+s"(fill));
@@ -1698,8 +1701,14 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
         load_tile(src);  // this tile again (the next one was on its way)
         break;
       }
+      const int before = qtot;
       if (any0) enqueue(pass[0], any0, col, kDoE ? 0 : 1, t * 32 + 16 * half);
       if (any1) enqueue(pass[1], any1, 32 + col, kDoE ? 0 : 1, t * 32 + 16 * half);
+      if (qtot - before > kDensePairs) {
+        ++t;
+        xsrc += 16;
+        break;
+      }
     }
     if constexpr (kDoE) {  // the vectors of k n1 and n2 come back for the full tests (unconditionally: they are dead inside the early loop)
       int at = lane;
