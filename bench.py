@@ -76,11 +76,11 @@ def load_traffic():
         return json.load(f), os.path.relpath(files[-1], ROOT)
 
 
-def traffic_of(table, prefix):
+def traffic_of(table, prefix, suffix=None):
     """Memory-side bytes per CALL of the kernels whose name starts with prefix: the probe makes each call on one shape only,
     so every (instantiation, grid) row of that name is one launch of the call (the exact scorer launches one model at a
     time and the nearly empty last round of a grid apart): (sum over the rows, {row: bytes})."""
-    rows = {k: v["bytes_per_launch"] for k, v in table.items() if k.startswith(prefix)}
+    rows = {k: v["bytes_per_launch"] for k, v in table.items() if k.startswith(prefix) and (suffix is None or suffix in k)}
     return (sum(rows.values()), rows) if rows else (None, None)
 
 
@@ -113,7 +113,7 @@ def kernel_counters(table, needle, per_call=False, kernel_ms=None):
     return {}
 
 
-def kernel_counters_sum(table, needle, kernel_ms):
+def kernel_counters_sum(table, needle, kernel_ms, also=None):
     """Counters of a library call that is made of one launch of each of several instantiations of a kernel (the exact E/H
     scorer runs one launch per model on large blocks).  Per instantiation that has launches of that size at all: the
     group of profiled launches, among those lasting between 0.15 and 1.0 x kernel_ms, with the most launches (the timing
@@ -126,6 +126,8 @@ def kernel_counters_sum(table, needle, kernel_ms):
     entries = []
     for name, c in table.items():
         groups = c.get("__clusters", {})
+        if also is not None and also not in name:  # `also`: a second part of the name (template arguments) that must be there too
+            continue
         if needle in name and any(lo <= r[0] <= hi for r in groups.get("SQ_INSTS_VALU", [])):
             entries.append(groups)
     if len(entries) < 2:
@@ -1187,10 +1189,15 @@ def main():
         table, counters_file = load_profile_counters(n, B)
         traffic_table, traffic_file = load_traffic()
         default_shape = (n, B) == (10000, 1000000)
-        traffic, traffic_parts = traffic_of(traffic_table, "eh_score_mfma2_kernel") if default_shape else (None, None)
+        # the instantiations without early loops end in ", false>" (a traffic file from before the early loops existed has no such suffix)
+        traffic, traffic_parts = (traffic_of(traffic_table, "eh_score_mfma2_kernel", ", false> grid") if default_shape else (None, None))
+        if default_shape and traffic is None and not any(", true> grid" in k for k in traffic_table if k.startswith("eh_score_mfma2_kernel")):
+            traffic, traffic_parts = traffic_of(traffic_table, "eh_score_mfma2_kernel")
         bound_issue = issue_roofline(kern_ms, kernel_counters_sum(table, "eh_upper_mfma2_kernel", kern_ms)
                                      or kernel_counters(table, "eh_upper_mfma_kernel<true, true", per_call=True))
-        exact_issue = issue_roofline(mixed_ms, kernel_counters_sum(table, "eh_score_mfma2_kernel", mixed_ms)
+        # the instantiations without early loops are <..., false>; a counters file from before the early loops existed has no such argument
+        has_forms = bool(table) and any("eh_score_mfma2_kernel" in k and ", true>(" in k for k in table)
+        exact_issue = issue_roofline(mixed_ms, kernel_counters_sum(table, "eh_score_mfma2_kernel", mixed_ms, ", false>(" if has_forms else None)
                                      or kernel_counters(table, "eh_score_mfma2_kernel", kernel_ms=mixed_ms))
         if bound_issue is not None and default_shape:
             bound_issue["memory_bytes_per_call"] = (traffic_of(traffic_table, "eh_upper_mfma2_kernel")[0]

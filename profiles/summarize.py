@@ -80,24 +80,29 @@ def main(d, json_out=None):
                 if not hit and i + 1 < len(big) and big[i + 1][1] < en:
                     hit = True
                 if not hit:
-                    alone.setdefault(name[:60], []).append((en - st) / 1e3)
+                    alone.setdefault(name[:76], []).append((en - st) / 1e3)  # up to the last template argument (early loops or not)
             if alone:
                 print("\n== launches of the exact E/H scorer that run alone on the device (us): instantiation | launches by duration group: count x average ==")
-                call = 0.0
+                call = {False: 0.0, True: 0.0}  # per form: without / with the early loops (last template argument)
                 for name, durs in alone.items():
                     groups = clusters([(0.0, x * 1e3) for x in durs])
                     txt = "  ".join(f"{g[2]} x {g[0]:.1f}" for g in groups)
-                    print(f"{name:60s} | {txt}")
+                    print(f"{name:76s} | {txt}")
                     # the groups of the default workload: the most frequent long group (main launch) and, for the E launch, the most frequent short one (its last round)
                     main = max((g for g in groups if g[0] > 1000.0), key=lambda g: g[2], default=None)
                     tail = max((g for g in groups if g[0] < 400.0), key=lambda g: g[2], default=None)
+                    early = ", true>" in name
                     if main:
-                        call += main[0]
-                    if tail and "true, false" in name:
-                        call += tail[0]
-                if call:
-                    print(f"one call on the default workload = E main launch + E last round + H launch: {call:.1f} us (bench.py roofline.kernel_ms also holds the operand preparation, ~10 us)")
-                    counters["__exact_call_alone_us"] = {"sum_of_launches_us": call}
+                        call[early] += main[0]
+                    if tail and "<true, false" in name:
+                        call[early] += tail[0]
+                if call[False]:
+                    print(f"one call on the default workload WITHOUT early loops (what `value` times) = E main launch + E last round + H launch: {call[False]:.1f} us "
+                          "(bench.py roofline.kernel_ms also holds the operand preparation, ~10 us)")
+                    counters["__exact_call_alone_us"] = {"sum_of_launches_us": call[False]}
+                if call[True]:
+                    print(f"one call WITH early loops (exact_counts_early_out.kernel_ms) = E main launch + E last round + H launch: {call[True]:.1f} us")
+                    counters["__exact_early_call_alone_us"] = {"sum_of_launches_us": call[True]}
         except Exception as e:  # schema differences between rocprofv3 versions
             print("  (per-dispatch listing unavailable:", e, ")")
     for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
@@ -144,7 +149,9 @@ def main(d, json_out=None):
                 groups = clusters([(0.0, x * 1e3) for x in durs])
                 for avg_us, _, cnt in groups:
                     print(f"{name:100s} | {cnt:4d} | {avg_us:10.1f}")
-                key = "exact E/H call (eh_score_mfma2: E main + E last round + H)" if "eh_score_mfma2" in name else None
+                key = None
+                if "eh_score_mfma2" in name:
+                    key = ("exact E/H call with early loops" if ", true>(" in name else "exact E/H call without early loops") + " (eh_score_mfma2: E main + E last round + H)"
                 if key:
                     total[key] = total.get(key, 0.0) + sum(g[0] for g in groups)
             for k, v in total.items():

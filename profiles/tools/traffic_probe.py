@@ -1,7 +1,7 @@
 """Memory-side traffic of the scoring kernels against bytes that are known, one launch at a time.
 
     python3 profiles/tools/traffic_probe.py run [matches:hypotheses ...]
-        launches, per shape, the exact E/H scorer (sfm_eh_score_mixed: one launch per model from 2^28 pairs on), the bound
+        launches, per shape, the exact E/H scorer without and with its early loops (sfm_eh_score_mixed_opt: one launch per model), the bound
         kernel (sfm_eh_upper_mfma) and, once, the exact translation scorer on the benchmark's secondary workload
         (12 cameras x 50 000 correspondences x 100 000 hypotheses), with a device synchronisation after every call.
         Run it under `rocprofv3 --pmc FETCH_SIZE --output-format csv` and again under `--pmc WRITE_SIZE`.
@@ -41,7 +41,9 @@ def run(args):
         idx = ops.index_sets(7, 0, nb, n)
         torch.cuda.synchronize()
         for rep in range(3):
-            ops.eh_score_mixed(corr, idx, thr, 3 * thr)
+            ops.eh_score_mixed(corr, idx, thr, 3 * thr, every_pair_full_test=True)  # instantiations <..., false>: what bench.py's `value` times
+            torch.cuda.synchronize()
+            ops.eh_score_mixed(corr, idx, thr, 3 * thr, every_pair_full_test=False)  # instantiations <..., true>: with the early loops
             torch.cuda.synchronize()
             ops.eh_upper_mfma(corr, corrm, idx, thr, 3 * thr)
             torch.cuda.synchronize()

@@ -1409,12 +1409,13 @@ __global__ __launch_bounds__(kBlock, 3) void eh_upper_mfma2_kernel(const double4
   }
 }
 
-template <bool kDoE, bool kDoH, int kMinBlocks>
+template <bool kDoE, bool kDoH, int kMinBlocks, bool kEarly>
 __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(const double4* __restrict__ corr, const uint4* __restrict__ pieces,
                                                                             const float2* __restrict__ xy, int n,
                                                                             const int32_t* __restrict__ idx, long long nb, double two_thr_e2,
                                                                             double thr_h2, double xmax, int* __restrict__ count_e,
-                                                                            int* __restrict__ count_h, int tiles_per_split, int use_atomics, int early) {
+                                                                            int* __restrict__ count_h, int tiles_per_split, int use_atomics) {
+  constexpr bool early = kEarly;  // an instantiation of its own: the form without early loops is the code it was before they existed
   constexpr int kModel = 9 * ((kDoE ? 1 : 0) + (kDoH ? 1 : 0));  // doubles per hypothesis parked for the float64 re-evaluation
   constexpr bool kPark = kDoE != kDoH;          // a one-model instantiation keeps some piece vectors in LDS, see below
   constexpr int kParkedE = 0;  // piece vectors of the second hypothesis group that the E-only instantiation keeps in LDS
@@ -1505,7 +1506,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
               bstage[lane][0][1]);
     pack_form(fma(e[0], e[0], e[1] * e[1]), 2.0 * fma(e[0], e[3], e[1] * e[4]), fma(e[3], e[3], e[4] * e[4]), 2.0 * fma(e[0], e[6], e[1] * e[7]),
               2.0 * fma(e[3], e[6], e[4] * e[7]), fma(e[6], e[6], e[7] * e[7]) + n2_offset, true, bstage[lane][1][0], bstage[lane][1][1]);
-    {
+    if constexpr (kEarly) {
       // the early test s^2 < k1 n1 + c of eh_upper_mfma2_kernel (safety factor 2): a pair that fails it is no float64 inlier
       const double en1 = (kn * N1b + 0x1.02p-9 * xm * xm * q1ab) * 1.0001;
       const double n1_ref = A[2] * A[2] + A[5] * A[5] + xm * xm / 3.0 * (A[0] * A[0] + A[1] * A[1] + A[3] * A[3] + A[4] * A[4]);
@@ -1516,7 +1517,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
                 2.0 * k1 * fma(e[0], e[2], e[3] * e[5]), 2.0 * k1 * fma(e[1], e[2], e[4] * e[5]), k1 * fma(e[2], e[2], e[5] * e[5]) + cst, true,
                 bstage[lane][2][0], bstage[lane][2][1]);
     }
-    fetch_round(BE, 3, 3);
+    fetch_round(BE, 3, kEarly ? 3 : 2);
   }
   if constexpr (kDoH) {
     double A[9];
@@ -3352,7 +3353,7 @@ static int run_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx,
     static const int early_default = !(getenv("SFM_HIP_EHX_EARLY") && atoi(getenv("SFM_HIP_EHX_EARLY")) == 0);
     const int early_env = (early_default && !(options & SFM_EHX_EVERY_PAIR_FULL_TEST)) ? 1 : 0;
     static const bool cut_tail = !(getenv("SFM_HIP_EHX_TAIL") && atoi(getenv("SFM_HIP_EHX_TAIL")) == 0);
-    static const long long slots_e = chip_slots(eh_score_mfma2_kernel<true, false, 3>), slots_h = chip_slots(eh_score_mfma2_kernel<false, true, 4>);
+    static const long long slots_e = chip_slots(eh_score_mfma2_kernel<true, false, 3, false>), slots_h = chip_slots(eh_score_mfma2_kernel<false, true, 4, false>);
     auto launch_model = [&](bool model_e, long long slots) -> int {
       auto one = [&](long long t_lo, long long t_hi, int sp, bool zeroed) -> int {
         const long long off = t_lo * kBlock;
@@ -3361,12 +3362,15 @@ static int run_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx,
         if (sp > 1 && !zeroed) SFM_TRY(hipMemsetAsync(dst, 0, sizeof(int32_t) * cnt, st));
         const dim3 g((unsigned)(t_hi - t_lo), sp);
         const int tp = div_up(ntiles, sp);
-        if (model_e)
-          eh_score_mfma2_kernel<true, false, 3><<<g, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, 2.0 * thr_e * thr_e,
-                                                                     thr_h * thr_h, xmax, count_e + off, count_h + off, tp, sp > 1, early_env);
-        else
-          eh_score_mfma2_kernel<false, true, 4><<<g, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, 2.0 * thr_e * thr_e,
-                                                                     thr_h * thr_h, xmax, count_e + off, count_h + off, tp, sp > 1, early_env);
+#define SFM_LAUNCH_EHX(E_, H_, W_, EARLY_)                                                                                                  \
+  eh_score_mfma2_kernel<E_, H_, W_, EARLY_><<<g, kBlock, 0, st>>>((const double4*)corr, pieces, xy, n, idx + 12 * off, cnt, 2.0 * thr_e * thr_e, \
+                                                                  thr_h * thr_h, xmax, count_e + off, count_h + off, tp, sp > 1)
+        if (model_e) {
+          if (early_env) SFM_LAUNCH_EHX(true, false, 3, true); else SFM_LAUNCH_EHX(true, false, 3, false);
+        } else {
+          if (early_env) SFM_LAUNCH_EHX(false, true, 4, true); else SFM_LAUNCH_EHX(false, true, 4, false);
+        }
+#undef SFM_LAUNCH_EHX
         return check_launch();
       };
       const long long rem = slots > 0 ? tiles % slots : 0;
