@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma_kernel(const
 // C = 3 eS; the C term is bounded by a multiple of S_c for every pair whose sign can be wrong and rides in B (see below);
 // A and B are doubled (safety) and rounded up.
 // ---------------------------------------------------------------------------------------
-constexpr int kEhxVecA = 6;  // match-side vectors per match: S1, S2 (six of the nine monomials of s), N1, N2 (the monomials of n1, n2), A1 = (x1, y1, 1) for the H test, S3 = (x1, y1, 1) in the five-product layout
+constexpr int kEhxVecA = 8;  // match-side vectors per match: S1, S2, S3 (the nine monomials of s, five piece products each), N1, N2 (the forms n1, n2), A1 = (x1, y1, 1) for the H test, T1, T2 (the nine monomials of s with three products each: the early test)
 
 // 5-term piece products of three monomials: hypothesis side (q0 q0 q1 q0 q2), match side (m0 m1 m0 m2 m0), 15 of 16 slots
 __device__ __forceinline__ void pack_quad(double a, double b, double c, bool model, uint4& lo, uint4& hi) {
@@ -1070,6 +1070,27 @@ __device__ __forceinline__ void pack_form(double xx, double xy, double yy, doubl
   hi = make_uint4(e[8] | (e[9] << 16), e[10] | (e[11] << 16), e[12] | (e[13] << 16), e[14] | (e[15] << 16));
 }
 
+// Three piece products (m0 c0, m1 c0, m0 c1) of up to five monomials in one operand vector (relative error of a kept triple
+// 3.1 * 2^-18); unused slots are zero.
+template <int kCount>
+__device__ __forceinline__ void pack_tri(const double (&v)[kCount], bool model, uint4& lo, uint4& hi) {
+  static_assert(kCount <= 5, "16 slots");
+  unsigned p[3], e[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) e[i] = 0;
+#pragma unroll
+  for (int m = 0; m < kCount; ++m) {
+    split3_bf16(v[m], p);
+    if (model) {
+      e[3 * m] = p[0]; e[3 * m + 1] = p[0]; e[3 * m + 2] = p[1];
+    } else {
+      e[3 * m] = p[0]; e[3 * m + 1] = p[1]; e[3 * m + 2] = p[0];
+    }
+  }
+  lo = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+  hi = make_uint4(e[8] | (e[9] << 16), e[10] | (e[11] << 16), e[12] | (e[13] << 16), e[14] | (e[15] << 16));
+}
+
 // pieces[tile][vector][match of the tile][half]: a wave's load of one vector of one tile is 1 KB of consecutive bytes
 __global__ __launch_bounds__(kBlock) void corr_to_mfma3_kernel(const double4* __restrict__ corr, int n, int npad, uint4* __restrict__ pieces,
                                                                float2* __restrict__ xy) {
@@ -1085,6 +1106,9 @@ __global__ __launch_bounds__(kBlock) void corr_to_mfma3_kernel(const double4* __
       pack_form(c.z * c.z, c.z * c.w, c.w * c.w, c.z, c.w, 1.0, false, out[192], out[193]);
       pack_pieces(c.x, c.y, 1.0, false, out[256], out[257]);
       pack_quad(c.x, c.y, 1.0, false, out[320], out[321]);
+      const double t1[5] = {c.z * c.x, c.z * c.y, c.w * c.x, c.w * c.y, c.z}, t2[4] = {c.w, c.x, c.y, 1.0};
+      pack_tri<5>(t1, false, out[384], out[385]);
+      pack_tri<4>(t2, false, out[448], out[449]);
       xy[j] = make_float2((float)c.z, (float)c.w);
     } else {
 #pragma unroll
@@ -1117,7 +1141,7 @@ __global__ __launch_bounds__(kBlock) void corr_to_mfma3_kernel(const double4* __
 // Match-side operands: those of eh_upper_mfma_kernel (piece vector of (x1, y1, 1), (x2, y2) / sqrt(k1), trailer) followed by
 // evec[tile][S1, S2, S3, N1][match of the tile][half]: 168 bytes per match.
 // ---------------------------------------------------------------------------------------
-constexpr int kUp2Vec = 4;
+constexpr int kUp2Vec = 3;
 
 __global__ __launch_bounds__(kBlock) void corr_to_upper2_kernel(const double4* __restrict__ corr, int n, int npad, double inv_sqrt_k1,
                                                                 uint4* __restrict__ pieces, float2* __restrict__ xy, uint4* __restrict__ evec) {
@@ -1130,10 +1154,10 @@ __global__ __launch_bounds__(kBlock) void corr_to_upper2_kernel(const double4* _
       c = corr[j];
       pack_pieces(c.x, c.y, 1.0, false, pieces[2 * j], pieces[2 * j + 1]);
       xy[j] = make_float2((float)(c.z * inv_sqrt_k1), (float)(c.w * inv_sqrt_k1));
-      pack_quad(c.z * c.x, c.z * c.y, c.w * c.x, false, out[0], out[1]);
-      pack_quad(c.w * c.y, c.z, c.w, false, out[64], out[65]);
-      pack_quad(c.x, c.y, 1.0, false, out[128], out[129]);
-      pack_form(c.x * c.x, c.x * c.y, c.y * c.y, c.x, c.y, 1.0, false, out[192], out[193]);
+      const double t1[5] = {c.z * c.x, c.z * c.y, c.w * c.x, c.w * c.y, c.z}, t2[4] = {c.w, c.x, c.y, 1.0};
+      pack_tri<5>(t1, false, out[0], out[1]);
+      pack_tri<4>(t2, false, out[64], out[65]);
+      pack_form(c.x * c.x, c.x * c.y, c.y * c.y, c.x, c.y, 1.0, false, out[128], out[129]);
     } else {
       pieces[2 * j] = pieces[2 * j + 1] = make_uint4(0, 0, 0, 0);
       xy[j] = make_float2(0.0f, 0.0f);
@@ -1162,7 +1186,7 @@ __global__ __launch_bounds__(kBlock, 3) void eh_upper_mfma2_kernel(const double4
   const int npad_all = ((n + 31) / 32) * 32;
   const double xm = usable_xmax(xmax, reinterpret_cast<const unsigned*>(xy + npad_all)[2]);
   constexpr bool kPark = kDoE && kDoH;
-  bf16x8 BE[2][kDoE ? 4 : 1], BH[2][kDoH ? 3 : 1];
+  bf16x8 BE[2][kDoE ? 3 : 1], BH[2][kDoH ? 3 : 1];
   {
     double Ed[9], Hd[9], A[9];
     float unused[9];
@@ -1192,8 +1216,11 @@ __global__ __launch_bounds__(kBlock, 3) void eh_upper_mfma2_kernel(const double4
       const double R0 = xm * (A[0] + A[1]) + A[2], R1 = xm * (A[3] + A[4]) + A[5], R2 = xm * (A[6] + A[7]) + A[8];
       const double Sb = xm * (R0 + R1) + R2, N1b = R0 * R0 + R1 * R1;
       const double u = kEps32;
-      const double es = (1.1 * 0x1.0p-18 / u * Sb + 32.0 * (1.0 + 0x1.0p-5) * (3.0 * xm * xm * (A[0] + A[1] + A[3]) + 2.0 * (xm * xm * A[4] + xm * (A[2] + A[5])) +
-                                                                              (xm * (A[6] + A[7]) + A[8]))) * u;
+      // |s_c - s|: three of the nine piece products of every monomial are kept (3.1 * 2^-18 Sb); the two MFMAs of the chain hold
+      // the terms of (x2 x1, x2 y1, y2 x1, y2 y1, x2) and of (y2, x1, y1, 1) in this order, and each adds at most 32 u (its own
+      // terms + what it is handed), so the first group's magnitude is counted twice
+      const double es = (3.1 * 0x1.0p-18 / u * Sb + 32.0 * (1.0 + 0x1.0p-5) * (2.0 * (xm * xm * (A[0] + A[1] + A[3] + A[4]) + xm * A[2]) +
+                                                                              (xm * (A[5] + A[6] + A[7]) + A[8]))) * u;
       const double q1ab = 2.0 * fabs(fma(e[0], e[1], e[3] * e[4]));
       const double kn = 3.1 * 0x1.0p-18 + 34.0 * u;
       const double en1 = (kn * N1b + 0x1.02p-9 * xm * xm * q1ab) * 1.0001;
@@ -1217,17 +1244,17 @@ __global__ __launch_bounds__(kBlock, 3) void eh_upper_mfma2_kernel(const double4
         lam = ldexp(1.0, lg);
       }
       const double l2 = lam * lam * k1;
-      pack_quad(e[0] * lam, e[1] * lam, e[3] * lam, true, bstage[wave][lane][0][0], bstage[wave][lane][0][1]);
-      pack_quad(e[4] * lam, e[2] * lam, e[5] * lam, true, bstage[wave][lane][1][0], bstage[wave][lane][1][1]);
-      pack_quad(e[6] * lam, e[7] * lam, e[8] * lam, true, bstage[wave][lane][2][0], bstage[wave][lane][2][1]);
+      const double c1[5] = {e[0] * lam, e[1] * lam, e[3] * lam, e[4] * lam, e[2] * lam}, c2[4] = {e[5] * lam, e[6] * lam, e[7] * lam, e[8] * lam};
+      pack_tri<5>(c1, true, bstage[wave][lane][0][0], bstage[wave][lane][0][1]);
+      pack_tri<4>(c2, true, bstage[wave][lane][1][0], bstage[wave][lane][1][1]);
       pack_form(l2 * fma(e[0], e[0], e[3] * e[3]), 2.0 * l2 * fma(e[0], e[1], e[3] * e[4]), l2 * fma(e[1], e[1], e[4] * e[4]),
                 2.0 * l2 * fma(e[0], e[2], e[3] * e[5]), 2.0 * l2 * fma(e[1], e[2], e[4] * e[5]),
-                l2 * fma(e[2], e[2], e[5] * e[5]) + lam * lam * cst, true, bstage[wave][lane][3][0], bstage[wave][lane][3][1]);
+                l2 * fma(e[2], e[2], e[5] * e[5]) + lam * lam * cst, true, bstage[wave][lane][2][0], bstage[wave][lane][2][1]);
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) BE[k][v] = as_bf16x8(bstage[wave][32 * k + col][v][half]);
+        for (int v = 0; v < 3; ++v) BE[k][v] = as_bf16x8(bstage[wave][32 * k + col][v][half]);
       __syncthreads();
     }
     if constexpr (kDoH) {
@@ -1278,13 +1305,12 @@ __global__ __launch_bounds__(kBlock, 3) void eh_upper_mfma2_kernel(const double4
   const float4* xsrc = reinterpret_cast<const float4*>(xy + t0 * 32 + 16 * half);
   const uint4* esrc = evec + ((long long)t0 * (kUp2Vec * 32) + apos) * 2 + half;
   // every match-side operand is loaded one tile ahead, into the registers its last reader has just released
-  bf16x8 A, AS1, AS2, AS3, AN1;
+  bf16x8 A, AT1, AT2, AN1;
   float x2[kDoH ? 16 : 1], y2[kDoH ? 16 : 1];
   auto load_e = [&](const uint4* q) {
-    AS1 = as_bf16x8(q[0]);
-    AS2 = as_bf16x8(q[64]);
-    AS3 = as_bf16x8(q[128]);
-    AN1 = as_bf16x8(q[192]);
+    AT1 = as_bf16x8(q[0]);
+    AT2 = as_bf16x8(q[64]);
+    AN1 = as_bf16x8(q[128]);
   };
   auto load_xy = [&](const float4* q, int pair) {
     const float4 v = q[pair];
@@ -1301,10 +1327,9 @@ __global__ __launch_bounds__(kBlock, 3) void eh_upper_mfma2_kernel(const double4
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if constexpr (kDoE) {
-        f32x16 sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS1, BE[k][0], zero, 0, 0, 0);
-        const f32x16 nv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AN1, BE[k][3], zero, 0, 0, 0);
-        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS2, BE[k][1], sv, 0, 0, 0);
-        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS3, BE[k][2], sv, 0, 0, 0);
+        f32x16 sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT1, BE[k][0], zero, 0, 0, 0);
+        const f32x16 nv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AN1, BE[k][2], zero, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT2, BE[k][1], sv, 0, 0, 0);
         if (k == 1) load_e(enext);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -1440,6 +1465,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   double Ed[9], Hd[9];
   float ea_own = 0.0f, eb_own = 0.0f, gh_own = 0.0f;
   bf16x8 BE[2][kDoE ? 6 : 1], BH[2][kDoH ? 3 : 1];  // BE[.][5]: the form of the early test
+  bf16x8 BT[2][(kDoE && kEarly) ? 2 : 1];           // the early test's s: three piece products per monomial in two vectors
   {
     double p8[8][4], p4[4][4];
     gather_samples<double>(corr, n, idx + 12 * hyp, p8, p4);
@@ -1508,16 +1534,25 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
               2.0 * fma(e[3], e[6], e[4] * e[7]), fma(e[6], e[6], e[7] * e[7]) + n2_offset, true, bstage[lane][1][0], bstage[lane][1][1]);
     if constexpr (kEarly) {
       // the early test s^2 < k1 n1 + c of eh_upper_mfma2_kernel (safety factor 2): a pair that fails it is no float64 inlier
+      // its s comes from two chained MFMAs (terms of (x2 x1, x2 y1, y2 x1, y2 y1, x2), then of (y2, x1, y1, 1)), three piece products each
+      const double est = (3.1 * 0x1.0p-18 / u * Sb + 32.0 * (1.0 + 0x1.0p-5) * (2.0 * (xm * xm * (A[0] + A[1] + A[3] + A[4]) + xm * A[2]) +
+                                                                               (xm * (A[5] + A[6] + A[7]) + A[8]))) * u;
       const double en1 = (kn * N1b + 0x1.02p-9 * xm * xm * q1ab) * 1.0001;
       const double n1_ref = A[2] * A[2] + A[5] * A[5] + xm * xm / 3.0 * (A[0] * A[0] + A[1] * A[1] + A[3] * A[3] + A[4] * A[4]);
-      const double mu = fmin(0.5, fmax(0x1.0p-7, safety * es / sqrt(k * n1_ref)));
+      const double mu = fmin(0.5, fmax(0x1.0p-7, safety * est / sqrt(k * n1_ref)));
       const double k1 = k * (1.0 + mu) * (1.0 + 32.0 * kEps32);
-      const double cst = ((1.0 + 1.0 / mu) * (safety * es) * (safety * es) + safety * k1 * en1) / (1.0 - safety * kn) * 1.0001;
+      const double cst = ((1.0 + 1.0 / mu) * (safety * est) * (safety * est) + safety * k1 * en1) / (1.0 - safety * kn) * 1.0001;
       pack_form(k1 * fma(e[0], e[0], e[3] * e[3]), 2.0 * k1 * fma(e[0], e[1], e[3] * e[4]), k1 * fma(e[1], e[1], e[4] * e[4]),
                 2.0 * k1 * fma(e[0], e[2], e[3] * e[5]), 2.0 * k1 * fma(e[1], e[2], e[4] * e[5]), k1 * fma(e[2], e[2], e[5] * e[5]) + cst, true,
                 bstage[lane][2][0], bstage[lane][2][1]);
     }
     fetch_round(BE, 3, kEarly ? 3 : 2);
+    if constexpr (kEarly) {  // round 3: the two vectors of the early test's s
+      const double c1[5] = {e[0], e[1], e[3], e[4], e[2]}, c2[4] = {e[5], e[6], e[7], e[8]};
+      pack_tri<5>(c1, true, bstage[lane][0][0], bstage[lane][0][1]);
+      pack_tri<4>(c2, true, bstage[lane][1][0], bstage[lane][1][1]);
+      fetch_round(BT, 0, 2);
+    }
   }
   if constexpr (kDoH) {
     double A[9];
@@ -1624,6 +1659,22 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
       any = ballot64(amb != 0u);
     } while (any);
   };
+  // the same for both hypothesis groups of a tile in one pass (the early loops: nearly every tile has a pair to queue in either
+  // group, and a pass costs as much for one group as for two): bits 0-15 of `both` = group 0, bits 16-31 = group 1
+  auto enqueue2 = [&](unsigned both, unsigned long long any, int test_h, int first_match) {
+    do {
+      const bool act = both != 0u;
+      const int bit = __ffs((int)both) - 1;
+      both &= both - 1u;
+      const unsigned entry = ((unsigned)(first_match + 15 - (bit & 15)) << 7) | ((unsigned)test_h << 6) | (unsigned)(2 * (bit & 16) + col);
+      const int pos = qlen + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(any >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)any, 0u));
+      if (act) qbuf[wave][pos] = entry;
+      qlen += __popcll(any);
+      qtot += __popcll(any);
+      if (qlen > kQueue - 64) drain();
+      any = ballot64(both != 0u);
+    } while (any);
+  };
   __builtin_amdgcn_s_setprio(0);
   SFM_STAMP_BEGIN();
   // The match-side vectors of a tile are loaded one tile ahead: after the last MFMA of a tile has been issued their
@@ -1639,7 +1690,18 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
       AS3 = as_bf16x8(q[5 * 64]);
     }
   };
-  if (t0 < t1) load_tile(src);
+  bf16x8 AT1, AT2;
+  auto load_early = [&](const uint4* q) {  // what the early loop of the E launch reads of a tile
+    AT1 = as_bf16x8(q[6 * 64]);
+    AT2 = as_bf16x8(q[7 * 64]);
+    AN1 = as_bf16x8(q[2 * 64]);
+  };
+  if (t0 < t1) {
+    if constexpr (kDoE && kPark && kEarly)
+      load_early(src);
+    else
+      load_tile(src);
+  }
   int t = t0;
   // EARLY LOOP (one-model instantiations).  Each test is implied by a cheaper one whose failure proves a pair to be no float64
   // inlier: the symmetric epipolar test by the one-sided s^2 < k1 n1 + c of eh_upper_mfma2_kernel (four MFMAs and three
@@ -1658,7 +1720,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
       const unsigned vmask = tail_mask | fill;
       const bool more = t + 1 < t1;
       if (more) src += kEhxVecA * 64;
-      float x2[kDoH ? 16 : 1];
+      float x2[kDoH ? 16 : 1];  // (reloading each register for the next tile right after its last use was measured: 1 % slower)
       if constexpr (kDoH) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1671,11 +1733,10 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
       for (int k = 0; k < 2; ++k) {
         unsigned hp = 0;
         if constexpr (kDoE) {
-          f32x16 sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS1, BE[k][0], zero, 0, 0, 0);
+          f32x16 sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT1, BT[k][0], zero, 0, 0, 0);
           const f32x16 nv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AN1, BE[k][kDoE ? 5 : 0], zero, 0, 0, 0);
-          sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS2, BE[k][1], sv, 0, 0, 0);
-          sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AS3, BE[k][2], sv, 0, 0, 0);
-          if (k == 1) load_tile(src);
+          sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT2, BT[k][(kDoE && kEarly) ? 1 : 0], sv, 0, 0, 0);
+          if (k == 1) load_early(src);
 #pragma unroll
           for (int i = 0; i < 16; ++i) hp = __builtin_amdgcn_alignbit(hp, __float_as_uint(fma(sv[i], sv[i], -nv[i])), 31);  // < 0 <=> passes
           pass[k] = (hp | force_f64) & vmask;
@@ -1698,13 +1759,12 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
       }
       const unsigned long long any0 = ballot64(pass[0] != 0u), any1 = ballot64(pass[1] != 0u);
       if (__popcll(any0) + __popcll(any1) > kDenseRows) {
-        if (more) src -= kEhxVecA * 64;
-        load_tile(src);  // this tile again (the next one was on its way)
+        if (more) src -= kEhxVecA * 64;  // this tile again (the next one was on its way)
+        if constexpr (!kDoE) load_tile(src);
         break;
       }
       const int before = qtot;
-      if (any0) enqueue(pass[0], any0, col, kDoE ? 0 : 1, t * 32 + 16 * half);
-      if (any1) enqueue(pass[1], any1, 32 + col, kDoE ? 0 : 1, t * 32 + 16 * half);
+      if (any0 | any1) enqueue2(pass[0] | (pass[1] << 16), any0 | any1, kDoE ? 0 : 1, t * 32 + 16 * half);
       if (qtot - before > kDensePairs) {
         ++t;
         xsrc += 16;
@@ -1712,6 +1772,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
       }
     }
     if constexpr (kDoE) {  // the vectors of k n1 and n2 come back for the full tests (unconditionally: they are dead inside the early loop)
+      if (t < t1) load_tile(src);  // the early loop only ever loaded its own three vectors of a tile
       int at = lane;
       asm volatile("" : "+v"(at));
 #pragma unroll
