@@ -129,8 +129,8 @@ int sfm_eh_score_mixed_opt(const double* corr, int32_t n, const int32_t* idx, in
 
 /* sfm_eh_score_mixed for callers that cannot allocate device memory (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc): same counts, no workspace argument, and no hipMalloc / hipFree or other
- * allocating call inside.  It has no counterpart in the reference.  The match-side operands (200 bytes per match) go into
- * a fixed array inside the library, SFM_NOALLOC_MAX_MATCHES * 200 bytes (6.25 MiB) that every GPU the library runs on
+ * allocating call inside.  It has no counterpart in the reference.  The match-side operands (264 bytes per match) go into
+ * a fixed array inside the library, SFM_NOALLOC_MAX_MATCHES * 264 bytes (8.25 MiB) that every GPU the library runs on
  * holds until the process ends; n beyond that capacity is rejected with SFM_ETOOLARGE.  All calls on one GPU share
  * that array: calls that overlap on one GPU (different streams or threads) race; calls on one stream are safe.
  * The array used is the one of the GPU that owns `stream` (of the current GPU for a NULL stream); the kernels are
@@ -264,7 +264,7 @@ int sfm_index_sets_i32(uint64_t seed, uint64_t first_id, int64_t nb, int32_t n, 
  * on the bf16 matrix cores from three-piece bf16 splits of the float64 models and coordinates; the comparisons and the
  * counts stay on the vector ALU.
  * corrm: match-side operands written by sfm_corr_to_mfma FOR THE SAME thr_e (the second view's coordinates are stored
- * divided by the square root of the slackened threshold constant); sfm_corr_mfma_bytes(n) bytes (168 per match, rounded
+ * divided by the square root of the slackened threshold constant); sfm_corr_mfma_bytes(n) bytes (136 per match, rounded
  * up to 32 matches, + 16), 16-byte aligned. */
 int64_t sfm_corr_mfma_bytes(int32_t n);
 int sfm_corr_to_mfma(const double* corr, int32_t n, double thr_e, void* corrm, void* stream);

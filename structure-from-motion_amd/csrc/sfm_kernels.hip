@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(kBlock) void corr_to_mfma3_kernel(const double4* __
 // Matrix-core pre-filter, SECOND FORM (the one in use; eh_upper_mfma_kernel stays reachable with SFM_HIP_UPPER_FORM=0):
 // the one-sided epipolar test whole from the matrix cores.  s = x2^T E x1 is a bilinear form and k1 n1 = k1 |(E x1)_{0,1}|^2
 // a quadratic form in x1, i.e. contractions of match-side monomials with hypothesis-side coefficients, exactly as in
-// eh_score_mfma2_kernel: three chained MFMAs give s (vectors S1, S2, S3: five of the nine piece products per monomial) and
+// eh_score_mfma2_kernel: two chained MFMAs give s (vectors T1, T2: three of the nine piece products per monomial) and
 // one gives N = k1 n1 + c (vector N1: the whole quadratic form, the slack constant c riding in its constant term), so the
 // test s^2 < N costs ONE vector instruction per pair (plus the count) instead of five after the rows E x1.
 // Upper-bound property.  A float64 inlier has s^2 (n1 + n2) < k n1 n2, hence s^2 < k n1.  With |s_c - s| <= es
@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(kBlock) void corr_to_mfma3_kernel(const double4* __
 // coordinates below about 2^-12) reports the trivial bound.
 // The transfer half is the box test of eh_upper_mfma_kernel, unchanged.
 // Match-side operands: those of eh_upper_mfma_kernel (piece vector of (x1, y1, 1), (x2, y2) / sqrt(k1), trailer) followed by
-// evec[tile][S1, S2, S3, N1][match of the tile][half]: 168 bytes per match.
+// evec[tile][T1, T2, N1][match of the tile][half] (T1, T2: the nine monomials of s with three piece products each): 136 bytes per match.
 // ---------------------------------------------------------------------------------------
 constexpr int kUp2Vec = 3;
 
@@ -3378,7 +3378,7 @@ static int run_eh_score_mixed(const double* corr, int32_t n, const int32_t* idx,
   const int npad = padded32(n);
   const int ntiles = npad / 32;
   // SFM_HIP_EHX_FORM=0: the epipolar test from the rows E x1 and E^T x2 on the vector ALU (eh_score_mfma_kernel, 72 bytes of
-  // operands per match) instead of s, n1, n2 whole from the matrix cores (eh_score_mfma2_kernel, 200 bytes per match)
+  // operands per match) instead of s, n1, n2 whole from the matrix cores (eh_score_mfma2_kernel, 264 bytes per match)
   static const bool form2_env = !(getenv("SFM_HIP_EHX_FORM") && atoi(getenv("SFM_HIP_EHX_FORM")) == 0);
   const bool form2 = form2_env && n < (1 << 25);  // its queue entries keep the match index in 25 bits
   uint4* pieces = (uint4*)workspace;
