@@ -1,6 +1,6 @@
 """Randomised exactness sweep (the long form is run by hand on the GPU box; tests/test_gpu_stress.py runs a slice):
 
-    python tests/stress_gpu.py [n_configs] > profiles/<tag>_stress.txt
+    python tests/stress_gpu.py [n_configs [seed]] > profiles/<tag>_stress.txt
 
 For random scenes (inlier ratio, planar share, match count, noise, threshold) it checks that
   * sfm_eh_score_mixed (with its early loops and with every pair through the full tests) returns the counts of
@@ -83,4 +83,4 @@ def main(n_cfg, seed=2024):
 
 
 if __name__ == "__main__":
-    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 60))
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024))
