@@ -6,8 +6,12 @@
 // with scalar loads into SGPRs; the VALU only executes the residual arithmetic, with the
 // model in VGPRs and the point as the scalar operand of each instruction.  Counts are
 // accumulated per lane (compare + add-with-carry), so no cross-lane reduction is needed.
-// The one GEMM-shaped piece in this file, the 3x3 products of the bulk pre-filter, runs on the
-// bf16 matrix cores (eh_upper_mfma_kernel); the descriptor matcher in sfm_match.hip uses the int8 ones.
+// That is the all-float64 form (eh_score_kernel, t_score_kernel).  The forms in use take everything that is a contraction
+// of hypothesis-side coefficients with match-side monomials -- the bilinear form x2' E x1, the squared line norms, the rows
+// H x1 and the translation residuals -- from the bf16 matrix cores (three-piece splits of the float64 values), decide a
+// pair in float32 and re-evaluate it in float64 only inside a rigorous error band: eh_score_mfma2_kernel (exact E/H counts),
+// t_score_mfma_kernel (exact translation counts), eh_upper_mfma2_kernel (upper bounds for the bulk arg-max).  The
+// descriptor matcher in sfm_match.hip uses the int8 matrix cores.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
