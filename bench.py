@@ -3,11 +3,14 @@
 
 Workload, one GPU (--workload c2, the default for N=1): the synthetic two-view E+H RANSAC configuration: 10 000
 SIFT-like matches, 30 % inliers, 10^6 hypotheses.  One step = every hypothesis solved (8-point E and 4-point H model)
-and BOTH of the reference's residual tests decided for every (hypothesis, match) pair (sfm_eh_score_mixed: the float64
-inlier counts of every hypothesis), then the arg-max of the two count arrays (sfm_argmax_count_i32) and the merge of the
-winners.  `value` counts those decided residual tests per second; `roofline` prices the same kernel with the algorithmic
-57 flops per pair.  The bound-driven arg-max step (sfm_eh_best: matrix-core bounds for every pair, float64 only for the
-candidates; the same exact winner) is reported beside it as `effective_value` / `effective_ms_per_step`.
+and BOTH of the reference's residual tests decided for every (hypothesis, match) pair (sfm_eh_score_mixed_opt with
+SFM_EHX_EVERY_PAIR_FULL_TEST: the float64 inlier counts of every hypothesis, every pair through the full symmetric-epipolar
+and disc tests), then the arg-max of the two count arrays (sfm_argmax_count_i32) and the merge of the winners.  `value`
+counts those decided residual tests per second; `roofline` prices the same kernel with the algorithmic 57 flops per pair.
+Two faster steps that return the same winners are reported beside it, never as `value`: the library's default form of the
+same call, whose early loops count a pair out as soon as a cheaper implied test proves it to be no inlier
+(`exact_counts_early_out_value`: still the float64 counts of every hypothesis), and the bound-driven arg-max step
+(sfm_eh_best: matrix-core bounds for every pair, float64 only for the candidates; `effective_value`).
 
 Workload, several GPUs (--workload c5, the default for N>1; also runs on one GPU): 200 000 matches x 10^8
 hypotheses, STRONG scaling: the hypothesis ids [0, 10^8) are split into contiguous ranges, one per rank
@@ -1205,7 +1208,8 @@ def main():
         achieved = flops_per_launch / (mixed_ms * 1e-3) / 1e12
         roofline = {
             "bound": "valu_fp32",
-            "kernel": "eh_score_mfma2_kernel (one launch per model: <true, false, 3> for E and <false, true, 4> for H; the bilinear form "
+            "kernel": "eh_score_mfma2_kernel (one launch per model: <true, false, 3, false> for E and <false, true, 4, false> for H, the instantiations "
+            "WITHOUT early loops; the bilinear form "
             "s = x2^T E x1, the squared line norms and the row H x1 on the bf16 matrix cores from three-piece splits, the reference's symmetric "
             "epipolar and transfer tests in float32 for every pair, float64 for the pairs inside the rigorous error band; float64 model solve "
             "included)",
