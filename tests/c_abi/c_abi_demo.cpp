@@ -77,6 +77,31 @@ int main() {
       return 2;
     }
   }
+  // exact counts from the matrix cores + float32: with the early loops (options 0) and with every pair through the full tests
+  {
+    const int64_t xs_bytes = sfm_eh_score_mixed_workspace_bytes(nb, n);
+    void* d_xs;
+    int32_t *d_me, *d_mh;
+    CHECK(hipMalloc(&d_xs, xs_bytes));
+    CHECK(hipMalloc(&d_me, nb * sizeof(int32_t)));
+    CHECK(hipMalloc(&d_mh, nb * sizeof(int32_t)));
+    std::vector<int32_t> me(nb), mh(nb);
+    for (int options = 0; options <= SFM_EHX_EVERY_PAIR_FULL_TEST; ++options) {
+      CHECK(sfm_eh_score_mixed_opt(d_corr, n, d_idx, nb, thr, 3 * thr, xmax, options, d_xs, xs_bytes, d_me, d_mh, nullptr));
+      CHECK(hipMemcpy(me.data(), d_me, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+      CHECK(hipMemcpy(mh.data(), d_mh, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < nb; ++i) {
+        if (me[i] != ce[i] || mh[i] != ch[i]) {
+          fprintf(stderr, "sfm_eh_score_mixed_opt(options=%d): hypothesis %lld has (%d, %d), float64 (%d, %d)\n", options, (long long)i, me[i], mh[i],
+                  ce[i], ch[i]);
+          return 4;
+        }
+      }
+    }
+    CHECK(hipFree(d_xs));
+    CHECK(hipFree(d_me));
+    CHECK(hipFree(d_mh));
+  }
   // translation RANSAC: all-float64 against matrix cores + float32 with the float64 band
   const int m = 5000;
   const int64_t nbt = 20000;
