@@ -138,6 +138,11 @@ def test_c_abi_rejects_bad_arguments(env):
     off = np.zeros(70, np.int64)
     assert lib.sfm_t_ransac_f64(C.dptr(pts), C.hptr(off), 69, C.dptr(i2), 4, 1e-3, C.dptr(cnt), C.dptr(best), C.dptr(T), null) == EINVAL  # > 64 cameras
     assert lib.sfm_triangulate_f64(C.dptr(T), C.dptr(T), C.dptr(pts), C.dptr(pts), 8, 4, C.dptr(pts), null) == EINVAL  # ld < m
+    ws = torch.zeros(int(lib.sfm_eh_score_mixed_workspace_bytes(4, 16)) + 256, dtype=torch.uint8, device="cuda")
+    args = (C.dptr(corr), 16, C.dptr(idx), 4, 1e-3, 3e-3, 0.0)
+    assert lib.sfm_eh_score_mixed_opt(*args, 2, C.dptr(ws), ws.numel(), C.dptr(out), C.dptr(out), null) == EINVAL  # unknown option bit
+    assert lib.sfm_eh_score_mixed_opt(*args, 1, C.dptr(ws), 16, C.dptr(out), C.dptr(out), null) == EINVAL  # workspace too small
+    assert lib.sfm_eh_score_mixed_opt(*args, 1, C.dptr(ws), ws.numel(), C.dptr(out), C.dptr(out), null) == 0
     with pytest.raises(C.SfmHipError):
         C.check(EINVAL)
     # the library still works after rejected calls
