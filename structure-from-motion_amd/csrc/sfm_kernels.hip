@@ -1551,7 +1551,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
                 bstage[lane][2][0], bstage[lane][2][1]);
     }
     fetch_round(BE, 3, kEarly ? 3 : 2);
-    if constexpr (kEarly) {  // round 3: the two vectors of the early test's s
+    if constexpr (kEarly) {  // third staging pass: the two vectors of the early test's s
       const double c1[5] = {e[0], e[1], e[3], e[4], e[2]}, c2[4] = {e[5], e[6], e[7], e[8]};
       pack_tri<5>(c1, true, bstage[lane][0][0], bstage[lane][0][1]);
       pack_tri<4>(c2, true, bstage[lane][1][0], bstage[lane][1][1]);

@@ -580,7 +580,7 @@ def test_mixed_eh_scoring_in_other_coordinate_scales_and_near_the_epipoles(ops, 
 
 
 def test_previous_form_of_the_exact_scorer_still_agrees(ops, dev):
-    """SFM_HIP_EHX_FORM=0 keeps the round-2 form of the exact scorer reachable (it is read once per process: child process)."""
+    """SFM_HIP_EHX_FORM=0 keeps the previous form of the exact scorer (rows E x1 and E^T x2 from the matrix cores, the test on the vector ALU) reachable (it is read once per process: child process)."""
     import subprocess
     import sys
 
