@@ -81,8 +81,10 @@ def test_c2_full_size_properties(env, mixed_form):
     ce_p, ch_p = ops.eh_score(C.dev(corr_h[perm]), C.dev(inv[idx_h[sub]], np.int32), thr, 3 * thr)
     np.testing.assert_array_equal(ce_p.cpu().numpy(), ce_h[sub])
     np.testing.assert_array_equal(ch_p.cpu().numpy(), ch_h[sub])
-    # a sample against the oracle, including the winners
-    pick = np.concatenate([[iE, iH], np.random.default_rng(1).integers(0, B, 200)])
+    # a sample against the oracle: the winners, the 200 hypotheses with the most inliers of either model (the ones with the
+    # most pairs near a threshold) and 2000 random ones
+    pick = np.concatenate([[iE, iH], np.argsort(-ce_h, kind="stable")[:200], np.argsort(-ch_h, kind="stable")[:200],
+                           np.random.default_rng(1).integers(0, B, 2000)])
     oE, oH, _, _ = orc.score_EH_batch(x1, x2, idx_h[pick].astype(np.int64), thr)
     ok = np.array([len(set(r[:8])) == 8 and len(set(r[8:])) == 4 for r in idx_h[pick]])
     np.testing.assert_array_equal(ce_h[pick][ok], oE[ok])
