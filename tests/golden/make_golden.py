@@ -271,6 +271,63 @@ def gen_eh_ransac_many():
     save("eh_ransac_many.npz", **out)
 
 
+def traced_run_ransac_light(sc, seed, thr_px=1.0):
+    """traced_run_ransac for long runs on many matches: the two distance arrays of an iteration are reduced to the count as soon
+    as the second arrives (the full trace of a 100 000-iteration run on 8 000 matches would hold gigabytes)."""
+    cE, cH, pending = [], [], []
+    state = {"expect": 0}
+    o_epi, o_h, o_f = ra.epipolar_errors, ra.get_inlier_mask_H, ra.estimate_F_DLT
+    thr = thr_px / sc["K"][0][0]
+
+    def w_f(*a):
+        state["expect"] = 2  # the loop body calls epipolar_errors twice right after estimate_F_DLT (src/ransac_algorithm.py:94-102)
+        pending.clear()
+        return o_f(*a)
+
+    def w_epi(*a):
+        d = o_epi(*a)
+        if state["expect"] > 0:
+            pending.append(d)
+            state["expect"] -= 1
+            if state["expect"] == 0:
+                cE.append(int(((pending[0] ** 2 + pending[1] ** 2) / 2 < thr**2).sum()))
+                pending.clear()
+        return d
+
+    def w_h(*a):
+        m = o_h(*a)
+        cH.append(int(m.sum()))
+        return m
+
+    ra.estimate_F_DLT, ra.epipolar_errors, ra.get_inlier_mask_H = w_f, w_epi, w_h
+    try:
+        np.random.seed(seed)
+        R, T, inl = ra.run_ransac(sc["K"], sc["x1"], sc["x2"], thr_px)
+    finally:
+        ra.estimate_F_DLT, ra.epipolar_errors, ra.get_inlier_mask_H = o_f, o_epi, o_h
+    next_draws = np.random.randint(0, 2**31 - 1, size=4)
+    return R, T, inl, np.array(cE), np.array(cH), next_draws
+
+
+def gen_eh_ransac_large():
+    """Six seeded run_ransac runs of the reference on 4 000 and 8 000 matches at 30-50 % inliers: loops of thousands to tens of
+    thousands of iterations, i.e. several doubling blocks of the drop-in loop and its draw-ahead (same layout as eh_ransac_many)."""
+    out = {}
+    runs = []
+    for n, inl, pl, j in [(4000, 0.5, 0.5, 0), (4000, 0.4, 0.3, 1), (4000, 0.3, 0.6, 2), (8000, 0.5, 0.4, 3), (8000, 0.4, 0.6, 4), (8000, 0.33, 0.2, 5)]:
+        sseed, rseed = 7000 + 41 * j + n, 900 + 13 * j + n
+        sc = synthetic.two_view_scene(n=n, inlier_ratio=inl, planar_ratio=pl, seed=sseed)
+        R, T, m, cE, cH, nd = traced_run_ransac_light(sc, rseed)
+        tag = f"r{len(runs):02d}"
+        print("eh_ransac_large", tag, "n", n, "iterations", len(cH), "inliers", int(m.sum()), flush=True)
+        assert len(cE) == len(cH)
+        runs.append([n, inl, pl, sseed, rseed, len(cH)])
+        out.update({f"{tag}_R": R, f"{tag}_T": T, f"{tag}_inliers": np.packbits(m), f"{tag}_cE": cE.astype(np.uint16),
+                    f"{tag}_cH": cH.astype(np.uint16), f"{tag}_next_draws": nd})
+    out["runs"] = np.array(runs, np.float64)
+    save("eh_ransac_large.npz", **out)
+
+
 def gen_reconstruction():
     sc = synthetic.two_view_scene(n=500, inlier_ratio=0.75, planar_ratio=0.6, seed=51)
     rel = [synthetic.rot_y(0.05), synthetic.rot_x(0.02) @ synthetic.rot_y(0.04), synthetic.rot_y(-0.03)]
@@ -286,6 +343,9 @@ if __name__ == "__main__":
     if "--only-many" in sys.argv:
         gen_eh_ransac_many()
         sys.exit(0)
+    if "--only-large" in sys.argv:
+        gen_eh_ransac_large()
+        sys.exit(0)
     pack = gen_solvers_and_scoring()
     gen_decomp(*pack)
     gen_triangulate(pack[0], pack[1], pack[2])
@@ -294,4 +354,5 @@ if __name__ == "__main__":
     gen_reconstruction()
     gen_eh_ransac()
     gen_eh_ransac_many()
+    gen_eh_ransac_large()
     gen_t_ransac()

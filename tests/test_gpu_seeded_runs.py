@@ -20,14 +20,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def seeded_runs_report():
+def seeded_runs_report(fixture="eh_ransac_many.npz"):
     from oracle import sfm_oracle as orc
     from sfm_hip import _capi as C
     from sfm_hip import ops
     from sfm_hip import ransac_algorithm as ra
 
     C.load_library()
-    g = np.load(os.path.join(HERE, "golden", "eh_ransac_many.npz"), allow_pickle=False)
+    g = np.load(os.path.join(HERE, "golden", fixture), allow_pickle=False)
     rows = []
     for r, (n, inl, pl, sseed, rseed, iters) in enumerate(g["runs"]):
         n, sseed, rseed, iters = int(n), int(sseed), int(rseed), int(iters)
@@ -72,3 +72,20 @@ def test_thirty_seeded_runs_against_the_reference():
     # a run without a record event on a repeated-index sample must reproduce the reference; on this fixture all thirty do
     assert all(r["identical_to_reference"] for r in rows if r["record_events_on_repeated_index"] == 0)
     assert same == 30
+
+
+def test_six_long_seeded_runs_on_thousands_of_matches_against_the_reference():
+    """tests/golden/eh_ransac_large.npz: six seeded run_ransac runs of the reference on 4 000 and 8 000 matches at 30-50 %
+    inliers, 5 900 to 161 000 iterations each: the drop-in loop goes through its doubling blocks up to the largest, draws
+    ahead while the GPU scores (blocks of 2^24 pairs and more) and rewinds the global stream when the loop ends inside a
+    block; every count comes from the exact scorer with its early loops."""
+    rows = seeded_runs_report("eh_ransac_large.npz")
+    assert len(rows) == 6
+    checked = sum(r["iterations"] for r in rows)
+    assert checked > 300000
+    assert sum(r["count_mismatches_without_repeated_index"] for r in rows) == 0
+    same = sum(r["identical_to_reference"] for r in rows)
+    print(f"long seeded runs identical to the reference: {same} of 6; iterations compared: {checked}, "
+          f"{sum(r['iterations_with_repeated_index'] for r in rows)} of them with a repeated index, runs with a record event on one: "
+          f"{sum(r['record_events_on_repeated_index'] > 0 for r in rows)}")
+    assert all(r["identical_to_reference"] for r in rows if r["record_events_on_repeated_index"] == 0)
