@@ -175,6 +175,35 @@ def gen_t_ransac():
          best_count=int(counts.max()), next_draws=state_after)
 
 
+def gen_t_ransac_more():
+    """Three more seeded 100 000-iteration robust_estimate_T runs of the reference: 2 000 correspondences with 60 % outliers,
+    5 000 with 20 %, 40 with 30 % (all counts, the winner, the next draws of the global stream)."""
+    out = {}
+    runs = []
+    for j, (m, outl, sseed, rseed) in enumerate([(2000, 0.6, 23, 4321), (5000, 0.2, 24, 99), (40, 0.3, 25, 7)]):
+        sc = synthetic.resection_scene(m=m, outlier_ratio=outl, seed=sseed)
+        counts = []
+        orig = et.count_inliers
+
+        def rec(*a):
+            c = orig(*a)
+            counts.append(c)
+            return c
+
+        et.count_inliers = rec
+        try:
+            np.random.seed(rseed)
+            T = et.robust_estimate_T(sc["x_norm"], sc["X"], sc["K"], sc["R"], 1.0)
+        finally:
+            et.count_inliers = orig
+        counts = np.array(counts)
+        print("t_ransac_more", j, "m", m, "best", int(counts.max()), "at", int(np.argmax(counts)), flush=True)
+        runs.append([m, outl, sseed, rseed])
+        out.update({f"r{j}_T": T, f"r{j}_counts": counts.astype(np.uint16), f"r{j}_next_draws": np.random.randint(0, 2**31 - 1, size=4)})
+    out["runs"] = np.array(runs, np.float64)  # correspondences, outlier share, scene seed, run seed
+    save("t_ransac_more.npz", **out)
+
+
 def gen_lm():
     cams = []
     for k, (Kc, seed) in enumerate([(synthetic.K_DATASET5, 31), (synthetic.K_DATASET10, 32),
@@ -343,6 +372,9 @@ if __name__ == "__main__":
     if "--only-many" in sys.argv:
         gen_eh_ransac_many()
         sys.exit(0)
+    if "--only-t-more" in sys.argv:
+        gen_t_ransac_more()
+        sys.exit(0)
     if "--only-large" in sys.argv:
         gen_eh_ransac_large()
         sys.exit(0)
@@ -356,3 +388,4 @@ if __name__ == "__main__":
     gen_eh_ransac_many()
     gen_eh_ransac_large()
     gen_t_ransac()
+    gen_t_ransac_more()

@@ -140,6 +140,38 @@ def test_robust_estimate_T_matches_reference(sfm, golden):
     np.testing.assert_array_equal(np.random.randint(0, 2**31 - 1, size=4), g["next_draws"])
 
 
+@pytest.mark.parametrize("run", [0, 1, 2])
+def test_more_reference_runs_of_robust_estimate_T(sfm, golden, run):
+    """tests/golden/t_ransac_more.npz: three more seeded 100 000-iteration runs of the reference's robust_estimate_T (2 000
+    correspondences with 60 % outliers, 5 000 with 20 %, 40 with 30 %): the drop-in call returns the reference's T and
+    leaves the global stream where the reference leaves it, and the scoring entry point (exact counts from the matrix
+    cores and all-float64) reproduces every count of every sample of two different correspondences."""
+    import torch
+
+    from sfm_hip import _capi, ops
+
+    g = golden("t_ransac_more.npz")
+    m, outl, sseed, rseed = g["runs"][run]
+    m = int(m)
+    sc = synthetic.resection_scene(m=m, outlier_ratio=float(outl), seed=int(sseed))
+    np.random.seed(int(rseed))
+    T = sfm.robust_estimate_T(sc["x_norm"], sc["X"], sc["K"], sc["R"], 1.0)
+    np.testing.assert_allclose(T, g[f"r{run}_T"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_array_equal(np.random.randint(0, 2**31 - 1, size=4), g[f"r{run}_next_draws"])
+    want = g[f"r{run}_counts"].astype(np.int32)
+    B = want.shape[0]
+    np.random.seed(int(rseed))
+    idx = np.random.randint(0, m, size=2 * B).reshape(1, B, 2)
+    pts = ops.pack_points(_capi.dev(sc["R"].ravel()), _capi.dev(sc["X"]), _capi.dev(sc["x_norm"]))
+    distinct = idx[0, :, 0] != idx[0, :, 1]
+    for mixed in (True, False):
+        best, Tb, counts = ops.t_ransac(pts, [m], _capi.dev(idx, np.int32), 4.0 / sc["K"][0][0], mixed=mixed)
+        np.testing.assert_array_equal(counts.cpu().numpy()[0][distinct], want[distinct])
+        cnt, ind = ops.decode_best(best.cpu().numpy())
+        assert int(cnt[0]) == int(want.max())
+    assert int(distinct.sum()) > 0.9 * B
+
+
 def test_robust_estimate_T_returns_none_without_inliers(sfm):
     sc = synthetic.resection_scene(m=50, outlier_ratio=0.0, seed=3)
     x = sc["x_norm"].copy()
