@@ -35,6 +35,26 @@ def mixed_form(request, monkeypatch):
     return request.param
 
 
+@pytest.fixture(scope="session")
+def check_e2e_against_reference():
+    """Compares the result of a run_geometry (oracle or GPU package) on the scene and seed of tests/golden/e2e_reference.npz
+    with what the reference's own stage sequence produced."""
+
+    def check(g, got, next_draws):
+        np.testing.assert_array_equal(next_draws, g["next_draws"])
+        np.testing.assert_allclose(np.array(got["absolute_rotations"]), g["abs_rot"], atol=1e-9)
+        inl = np.asarray(got["inliers"]).astype(bool)
+        assert inl.shape[0] == int(g["n_inliers_bits"])
+        np.testing.assert_array_equal(np.packbits(inl), g["inliers"])
+        np.testing.assert_allclose(got["X0"], g["X0"], rtol=1e-6, atol=1e-7)
+        for a, b in zip(got["estimated_Ts"], g["estimated_Ts"]):
+            np.testing.assert_allclose(np.reshape(a, 3), b, rtol=1e-7, atol=1e-9)
+        for a, b in zip(got["refined_Ts"], g["refined_Ts"]):
+            np.testing.assert_allclose(np.reshape(a, 3), b, rtol=1e-7, atol=1e-9)
+
+    return check
+
+
 def has_gpu():
     try:
         import torch

@@ -204,6 +204,29 @@ def gen_t_ransac_more():
     save("t_ransac_more.npz", **out)
 
 
+def gen_e2e():
+    """The reference's own stage sequence (run_sfm.py:59-80: estimate_R, run_reconstruction, estimate_translation,
+    refine_translation) with one seed on a synthetic five-camera scene; OpenCV's matcher inside find_correspondences is
+    replaced by the scene's stand-in (bound into both modules that imported it with `from .utils import *`)."""
+    sc = synthetic.multi_view_scene(n_cams=5, n_points=900, seed=4)
+    o_et, o_rt = et.find_correspondences, rt.find_correspondences
+    et.find_correspondences = rt.find_correspondences = sc["find_correspondences"]
+    try:
+        np.random.seed(2024)
+        R_list = ra.estimate_R(sc["K"], sc["x_pairs"], 1.0)
+        X0, abs_rot, inl = r3.run_reconstruction(R_list, sc["init_pair_dict"], sc["K"], 1.0)
+        desc_X = sc["init_pair_dict"]["init_pair_desc"]
+        est = et.estimate_translation(sc["K"], desc_X, X0, abs_rot, sc["img_paths"], 1.0)
+        ref = rt.refine_translation(sc["K"], sc["img_paths"], desc_X[:, inl], X0, abs_rot, est)
+        nd = np.random.randint(0, 2**31 - 1, size=4)
+    finally:
+        et.find_correspondences, rt.find_correspondences = o_et, o_rt
+    assert all(t is not None for t in est)
+    save("e2e_reference.npz", scene=np.array([5, 900, 4]), seed=2024, R_rel=np.array(R_list), abs_rot=np.array(abs_rot), X0=X0,
+         inliers=np.packbits(inl), n_inliers_bits=np.array(inl.shape[0]), estimated_Ts=np.array([np.reshape(t, 3) for t in est]),
+         refined_Ts=np.array([np.reshape(t, 3) for t in ref]), next_draws=nd)
+
+
 def gen_lm():
     cams = []
     for k, (Kc, seed) in enumerate([(synthetic.K_DATASET5, 31), (synthetic.K_DATASET10, 32),
@@ -372,6 +395,9 @@ if __name__ == "__main__":
     if "--only-many" in sys.argv:
         gen_eh_ransac_many()
         sys.exit(0)
+    if "--only-e2e" in sys.argv:
+        gen_e2e()
+        sys.exit(0)
     if "--only-t-more" in sys.argv:
         gen_t_ransac_more()
         sys.exit(0)
@@ -389,3 +415,4 @@ if __name__ == "__main__":
     gen_eh_ransac_large()
     gen_t_ransac()
     gen_t_ransac_more()
+    gen_e2e()

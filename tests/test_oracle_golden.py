@@ -156,3 +156,15 @@ def test_reconstruction(golden):
     np.testing.assert_allclose(np.array(abs_rot), g["abs_rot"], atol=1e-12)
     np.testing.assert_array_equal(np.packbits(inl), g["inliers"])
     np.testing.assert_allclose(X0, g["X0"], rtol=1e-7, atol=1e-8)
+
+
+def test_whole_stage_sequence_against_the_reference_run(golden, check_e2e_against_reference):
+    """e2e_reference.npz: the REFERENCE's own estimate_R -> run_reconstruction -> estimate_translation -> refine_translation
+    with one seed on a synthetic five-camera scene (its OpenCV matcher replaced by the scene's stand-in): the oracle's
+    run_geometry must give the same rotations, cloud, inlier mask, translations and stream position."""
+    g = golden("e2e_reference.npz")
+    n_cams, n_points, seed = (int(v) for v in g["scene"])
+    sc = synthetic.multi_view_scene(n_cams=n_cams, n_points=n_points, seed=seed)
+    np.random.seed(int(g["seed"]))
+    got = orc.run_geometry(sc["K"], sc["x_pairs"], sc["init_pair_dict"], sc["img_paths"], 1.0, sc["find_correspondences"])
+    check_e2e_against_reference(g, got, np.random.randint(0, 2**31 - 1, size=4))
