@@ -227,6 +227,29 @@ def gen_e2e():
          refined_Ts=np.array([np.reshape(t, 3) for t in ref]), next_draws=nd)
 
 
+def gen_dlt_general():
+    """estimate_F_DLT / estimate_H_DLT of the reference on MORE than a minimal sample (they loop over every column they are
+    given): inlier subsets of 9, 20 and 150 matches of the scoring scene for F, 5, 12 and 90 exactly transferred points for H."""
+    sc = synthetic.two_view_scene(n=1500, inlier_ratio=0.5, planar_ratio=0.5, seed=11)
+    x1 = ut.normalize_K(sc["K"], sc["x1"])
+    x2 = ut.normalize_K(sc["K"], sc["x2"])
+    inl = np.flatnonzero(sc["is_inlier"])
+    rng = np.random.RandomState(8)
+    out = {"scene": np.array([1500, 0.5, 0.5, 11])}
+    for n in (9, 20, 150):
+        cols = inl[rng.permutation(len(inl))[:n]]
+        out[f"F_cols_{n}"] = cols
+        out[f"F_{n}"] = ra.estimate_F_DLT(x1[:, cols], x2[:, cols])
+    Hs = np.array([[1.02, 0.03, 0.01], [-0.02, 0.97, 0.04], [0.05, -0.03, 1.0]])
+    p1 = np.vstack([rng.uniform(-0.5, 0.5, (2, 90)), np.ones((1, 90))])
+    p2 = Hs @ p1
+    p2 = p2 / p2[2] + np.vstack([rng.normal(0, 1e-3, (2, 90)), np.zeros((1, 90))])
+    out["H_p1"], out["H_p2"] = p1, p2
+    for n in (5, 12, 90):
+        out[f"H_{n}"] = ra.estimate_H_DLT(p1[:, :n], p2[:, :n])
+    save("dlt_general.npz", **out)
+
+
 def gen_lm():
     cams = []
     for k, (Kc, seed) in enumerate([(synthetic.K_DATASET5, 31), (synthetic.K_DATASET10, 32),
@@ -395,6 +418,9 @@ if __name__ == "__main__":
     if "--only-many" in sys.argv:
         gen_eh_ransac_many()
         sys.exit(0)
+    if "--only-dlt" in sys.argv:
+        gen_dlt_general()
+        sys.exit(0)
     if "--only-e2e" in sys.argv:
         gen_e2e()
         sys.exit(0)
@@ -416,3 +442,4 @@ if __name__ == "__main__":
     gen_t_ransac()
     gen_t_ransac_more()
     gen_e2e()
+    gen_dlt_general()

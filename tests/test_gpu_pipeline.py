@@ -253,6 +253,24 @@ def test_single_model_functions(sfm, golden):
     assert et.count_inliers(rs["x_norm"], rs["X"], rs["R"], t["T"][j], float(t["thr"])) == t["counts"][j]
 
 
+def test_dlt_over_more_than_a_minimal_sample_against_the_reference(sfm, golden):
+    """dlt_general.npz: what the reference's estimate_F_DLT returns for 9, 20 and 150 matches and its estimate_H_DLT for 5, 12
+    and 90 points (F up to the sign of the null vector, which is LAPACK's choice there)."""
+    from sfm_hip import ransac_algorithm as ra
+
+    g = golden("dlt_general.npz")
+    sc = two_view(g["scene"])
+    x1 = orc.normalize_K(sc["K"], sc["x1"])
+    x2 = orc.normalize_K(sc["K"], sc["x2"])
+    for n in (9, 20, 150):
+        cols = g[f"F_cols_{n}"]
+        F = ra.estimate_F_DLT(x1[:, cols], x2[:, cols])
+        np.testing.assert_allclose(np.sign(np.sum(F * g[f"F_{n}"])) * F, g[f"F_{n}"], atol=1e-9)
+    for n in (5, 12, 90):
+        H = ra.estimate_H_DLT(g["H_p1"][:, :n], g["H_p2"][:, :n])
+        np.testing.assert_allclose(H, g[f"H_{n}"], rtol=1e-7, atol=1e-9)
+
+
 def test_dlt_over_any_number_of_correspondences(sfm, golden):
     """estimate_F_DLT and estimate_H_DLT of the reference loop over every column they are given (src/ransac_algorithm.py
     :240-253, :280-282): more than a minimal sample goes through sfm_dlt_general_f64.  The null vector of a well

@@ -168,3 +168,17 @@ def test_whole_stage_sequence_against_the_reference_run(golden, check_e2e_agains
     np.random.seed(int(g["seed"]))
     got = orc.run_geometry(sc["K"], sc["x_pairs"], sc["init_pair_dict"], sc["img_paths"], 1.0, sc["find_correspondences"])
     check_e2e_against_reference(g, got, np.random.randint(0, 2**31 - 1, size=4))
+
+
+def test_dlt_over_more_than_a_minimal_sample(golden):
+    """dlt_general.npz: the reference's estimate_F_DLT on 9, 20 and 150 matches and estimate_H_DLT on 5, 12 and 90 points
+    (F up to its sign: the null vector's sign is LAPACK's choice)."""
+    g = golden("dlt_general.npz")
+    sc, x1, x2 = scene_from(g["scene"])
+    for n in (9, 20, 150):
+        cols = g[f"F_cols_{n}"]
+        F = orc.estimate_F_DLT(x1[:, cols], x2[:, cols])
+        np.testing.assert_allclose(np.sign(np.sum(F * g[f"F_{n}"])) * F, g[f"F_{n}"], atol=1e-10)
+    for n in (5, 12, 90):
+        H = orc.estimate_H_DLT(g["H_p1"][:, :n], g["H_p2"][:, :n])
+        np.testing.assert_allclose(H, g[f"H_{n}"], rtol=1e-8, atol=1e-10)
