@@ -208,11 +208,16 @@ def gen_e2e():
     """The reference's own stage sequence (run_sfm.py:59-80: estimate_R, run_reconstruction, estimate_translation,
     refine_translation) with one seed on a synthetic five-camera scene; OpenCV's matcher inside find_correspondences is
     replaced by the scene's stand-in (bound into both modules that imported it with `from .utils import *`)."""
-    sc = synthetic.multi_view_scene(n_cams=5, n_points=900, seed=4)
+    gen_e2e_scene("e2e_reference.npz", dict(n_cams=5, n_points=900, seed=4), 2024)
+    gen_e2e_scene("e2e_reference_b.npz", dict(n_cams=7, n_points=1500, init_pair=(2, 4), seed=12), 77)
+
+
+def gen_e2e_scene(name, scene, run_seed):
+    sc = synthetic.multi_view_scene(**scene)
     o_et, o_rt = et.find_correspondences, rt.find_correspondences
     et.find_correspondences = rt.find_correspondences = sc["find_correspondences"]
     try:
-        np.random.seed(2024)
+        np.random.seed(run_seed)
         R_list = ra.estimate_R(sc["K"], sc["x_pairs"], 1.0)
         X0, abs_rot, inl = r3.run_reconstruction(R_list, sc["init_pair_dict"], sc["K"], 1.0)
         desc_X = sc["init_pair_dict"]["init_pair_desc"]
@@ -222,7 +227,8 @@ def gen_e2e():
     finally:
         et.find_correspondences, rt.find_correspondences = o_et, o_rt
     assert all(t is not None for t in est)
-    save("e2e_reference.npz", scene=np.array([5, 900, 4]), seed=2024, R_rel=np.array(R_list), abs_rot=np.array(abs_rot), X0=X0,
+    ip = scene.get("init_pair", (1, 3))  # the default of synthetic.multi_view_scene
+    save(name, scene=np.array([scene["n_cams"], scene["n_points"], scene["seed"]]), init_pair=np.array(ip), seed=run_seed, R_rel=np.array(R_list), abs_rot=np.array(abs_rot), X0=X0,
          inliers=np.packbits(inl), n_inliers_bits=np.array(inl.shape[0]), estimated_Ts=np.array([np.reshape(t, 3) for t in est]),
          refined_Ts=np.array([np.reshape(t, 3) for t in ref]), next_draws=nd)
 

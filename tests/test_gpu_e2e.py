@@ -44,16 +44,18 @@ def test_pipeline_matches_oracle_end_to_end(monkeypatch):
         assert ang < 0.02
 
 
-def test_pipeline_matches_the_reference_run_end_to_end(monkeypatch, golden, check_e2e_against_reference):
-    """tests/golden/e2e_reference.npz holds what the REFERENCE's own stage sequence (estimate_R, run_reconstruction,
+@pytest.mark.parametrize("fixture", ["e2e_reference.npz", "e2e_reference_b.npz"])
+def test_pipeline_matches_the_reference_run_end_to_end(monkeypatch, golden, check_e2e_against_reference, fixture):
+    """tests/golden/e2e_reference*.npz hold what the REFERENCE's own stage sequence (estimate_R, run_reconstruction,
     estimate_translation, refine_translation; its OpenCV matcher replaced by the scene's stand-in) returns for one seed on
-    a synthetic five-camera scene: the GPU package must return the same, down to the position of the global stream."""
+    a synthetic five-camera and on a seven-camera scene: the GPU package must return the same, down to the position of the
+    global stream."""
     from sfm_hip import _capi, pipeline, utils
 
     _capi.load_library()
-    g = golden("e2e_reference.npz")
+    g = golden(fixture)
     n_cams, n_points, seed = (int(v) for v in g["scene"])
-    sc = synthetic.multi_view_scene(n_cams=n_cams, n_points=n_points, seed=seed)
+    sc = synthetic.multi_view_scene(n_cams=n_cams, n_points=n_points, init_pair=tuple(int(v) for v in g["init_pair"]), seed=seed)
     monkeypatch.setattr(utils, "find_correspondences", sc["find_correspondences"])
     np.random.seed(int(g["seed"]))
     got = pipeline.run_geometry(sc["K"], sc["x_pairs"], sc["init_pair_dict"], sc["img_paths"], 1.0)

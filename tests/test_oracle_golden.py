@@ -164,7 +164,7 @@ def test_whole_stage_sequence_against_the_reference_run(golden, check_e2e_agains
     run_geometry must give the same rotations, cloud, inlier mask, translations and stream position."""
     g = golden("e2e_reference.npz")
     n_cams, n_points, seed = (int(v) for v in g["scene"])
-    sc = synthetic.multi_view_scene(n_cams=n_cams, n_points=n_points, seed=seed)
+    sc = synthetic.multi_view_scene(n_cams=n_cams, n_points=n_points, init_pair=tuple(int(v) for v in g["init_pair"]), seed=seed)
     np.random.seed(int(g["seed"]))
     got = orc.run_geometry(sc["K"], sc["x_pairs"], sc["init_pair_dict"], sc["img_paths"], 1.0, sc["find_correspondences"])
     check_e2e_against_reference(g, got, np.random.randint(0, 2**31 - 1, size=4))
