@@ -409,6 +409,26 @@ def gen_eh_ransac_large():
     save("eh_ransac_large.npz", **out)
 
 
+def gen_eh_ransac_thresholds():
+    """Six seeded run_ransac runs of the reference at pixel thresholds of 0.25, 2.5 and 8 (1 200 matches, two seeds each);
+    layout of eh_ransac_many with the threshold as a seventh column of `runs`."""
+    out = {}
+    runs = []
+    for thr_px in (0.25, 2.5, 8.0):
+        for j in range(2):
+            n, inl, pl = 1200, 0.5 + 0.1 * j, 0.4 + 0.2 * j
+            sseed, rseed = 3000 + 17 * j + int(100 * thr_px), 60 + 7 * j + int(10 * thr_px)
+            sc = synthetic.two_view_scene(n=n, inlier_ratio=inl, planar_ratio=pl, seed=sseed)
+            R, T, m, cE, cH, nd = traced_run_ransac_light(sc, rseed, thr_px)
+            tag = f"r{len(runs):02d}"
+            print("eh_ransac_thresholds", tag, "thr", thr_px, "iterations", len(cH), "inliers", int(m.sum()), flush=True)
+            runs.append([n, inl, pl, sseed, rseed, len(cH), thr_px])
+            out.update({f"{tag}_R": R, f"{tag}_T": T, f"{tag}_inliers": np.packbits(m), f"{tag}_cE": cE.astype(np.uint16),
+                        f"{tag}_cH": cH.astype(np.uint16), f"{tag}_next_draws": nd})
+    out["runs"] = np.array(runs, np.float64)
+    save("eh_ransac_thresholds.npz", **out)
+
+
 def gen_reconstruction():
     sc = synthetic.two_view_scene(n=500, inlier_ratio=0.75, planar_ratio=0.6, seed=51)
     rel = [synthetic.rot_y(0.05), synthetic.rot_x(0.02) @ synthetic.rot_y(0.04), synthetic.rot_y(-0.03)]
@@ -423,6 +443,9 @@ def gen_reconstruction():
 if __name__ == "__main__":
     if "--only-many" in sys.argv:
         gen_eh_ransac_many()
+        sys.exit(0)
+    if "--only-thresholds" in sys.argv:
+        gen_eh_ransac_thresholds()
         sys.exit(0)
     if "--only-dlt" in sys.argv:
         gen_dlt_general()
@@ -445,6 +468,7 @@ if __name__ == "__main__":
     gen_eh_ransac()
     gen_eh_ransac_many()
     gen_eh_ransac_large()
+    gen_eh_ransac_thresholds()
     gen_t_ransac()
     gen_t_ransac_more()
     gen_e2e()

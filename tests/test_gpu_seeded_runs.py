@@ -29,16 +29,18 @@ def seeded_runs_report(fixture="eh_ransac_many.npz"):
     C.load_library()
     g = np.load(os.path.join(HERE, "golden", fixture), allow_pickle=False)
     rows = []
-    for r, (n, inl, pl, sseed, rseed, iters) in enumerate(g["runs"]):
+    for r, row in enumerate(g["runs"]):
+        n, inl, pl, sseed, rseed, iters = row[:6]
+        thr_px = float(row[6]) if len(row) > 6 else 1.0  # a seventh column holds the pixel threshold of the run
         n, sseed, rseed, iters = int(n), int(sseed), int(rseed), int(iters)
         tag = f"r{r:02d}"
         sc = synthetic.two_view_scene(n=n, inlier_ratio=float(inl), planar_ratio=float(pl), seed=sseed)
         x1, x2 = orc.normalize_K(sc["K"], sc["x1"]), orc.normalize_K(sc["K"], sc["x2"])
-        thr = 1.0 / sc["K"][0][0]
+        thr = thr_px / sc["K"][0][0]
         np.random.seed(rseed)
         idx = np.random.randint(0, n, size=12 * iters).reshape(iters, 12)
-        repE = np.array([len(set(row[:8])) < 8 for row in idx])
-        repH = np.array([len(set(row[8:])) < 4 for row in idx])
+        repE = (np.diff(np.sort(idx[:, :8], axis=1), axis=1) == 0).any(axis=1)  # a sample that holds an index twice
+        repH = (np.diff(np.sort(idx[:, 8:], axis=1), axis=1) == 0).any(axis=1)
         ce, ch = ops.eh_score(C.dev(ops.pack_corr(x1, x2)), C.dev(idx, np.int32), thr, 3 * thr)
         ce, ch = ce.cpu().numpy(), ch.cpu().numpy()
         cE, cH = g[f"{tag}_cE"].astype(np.int64), g[f"{tag}_cH"].astype(np.int64)
@@ -88,4 +90,15 @@ def test_six_long_seeded_runs_on_thousands_of_matches_against_the_reference():
     print(f"long seeded runs identical to the reference: {same} of 6; iterations compared: {checked}, "
           f"{sum(r['iterations_with_repeated_index'] for r in rows)} of them with a repeated index, runs with a record event on one: "
           f"{sum(r['record_events_on_repeated_index'] > 0 for r in rows)}")
+    assert all(r["identical_to_reference"] for r in rows if r["record_events_on_repeated_index"] == 0)
+
+
+def test_seeded_runs_at_other_pixel_thresholds_against_the_reference():
+    """tests/golden/eh_ransac_thresholds.npz: six seeded run_ransac runs of the reference at thresholds of 0.25, 2.5 and 8 pixels."""
+    rows = seeded_runs_report("eh_ransac_thresholds.npz")
+    assert len(rows) == 6
+    assert sum(r["count_mismatches_without_repeated_index"] for r in rows) == 0
+    same = sum(r["identical_to_reference"] for r in rows)
+    print(f"runs at other thresholds identical to the reference: {same} of 6; iterations compared: {sum(r['iterations'] for r in rows)}, "
+          f"runs with a record event on a repeated-index sample: {sum(r['record_events_on_repeated_index'] > 0 for r in rows)}")
     assert all(r["identical_to_reference"] for r in rows if r["record_events_on_repeated_index"] == 0)
