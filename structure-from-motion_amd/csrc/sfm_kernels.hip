@@ -1468,6 +1468,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   uint4(*bstage)[4][2] = reinterpret_cast<uint4(*)[4][2]>(&stage_raw[wave][0]);  // [lane][vector of the round][half]
   double Ed[9], Hd[9];
   float ea_own = 0.0f, eb_own = 0.0f, gh_own = 0.0f;
+  unsigned early_all_own = 0u;  // 0xFFFF: every pair of this hypothesis passes the early test (its outcome cannot be produced exactly)
   bf16x8 BE[2][kDoE ? 6 : 1], BH[2][kDoH ? 3 : 1];  // BE[.][5]: the form of the early test
   bf16x8 BT[2][(kDoE && kEarly) ? 2 : 1];           // the early test's s: three piece products per monomial in two vectors
   {
@@ -1536,6 +1537,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
               bstage[lane][0][1]);
     pack_form(fma(e[0], e[0], e[1] * e[1]), 2.0 * fma(e[0], e[3], e[1] * e[4]), fma(e[3], e[3], e[4] * e[4]), 2.0 * fma(e[0], e[6], e[1] * e[7]),
               2.0 * fma(e[3], e[6], e[4] * e[7]), fma(e[6], e[6], e[7] * e[7]) + n2_offset, true, bstage[lane][1][0], bstage[lane][1][1]);
+    double elam = 1.0;
     if constexpr (kEarly) {
       // the early test s^2 < k1 n1 + c of eh_upper_mfma2_kernel (safety factor 2): a pair that fails it is no float64 inlier
       // its s comes from two chained MFMAs (terms of (x2 x1, x2 y1, y2 x1, y2 y1, x2), then of (y2, x1, y1, 1)), three piece products each
@@ -1545,14 +1547,29 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
       const double n1_ref = A[2] * A[2] + A[5] * A[5] + xm * xm / 3.0 * (A[0] * A[0] + A[1] * A[1] + A[3] * A[3] + A[4] * A[4]);
       const double mu = fmin(0.5, fmax(0x1.0p-7, safety * est / sqrt(k * n1_ref)));
       const double k1 = k * (1.0 + mu) * (1.0 + 32.0 * kEps32);
-      const double cst = ((1.0 + 1.0 / mu) * (safety * est) * (safety * est) + safety * k1 * en1) / (1.0 - safety * kn) * 1.0001;
-      pack_form(k1 * fma(e[0], e[0], e[3] * e[3]), 2.0 * k1 * fma(e[0], e[1], e[3] * e[4]), k1 * fma(e[1], e[1], e[4] * e[4]),
-                2.0 * k1 * fma(e[0], e[2], e[3] * e[5]), 2.0 * k1 * fma(e[1], e[2], e[4] * e[5]), k1 * fma(e[2], e[2], e[5] * e[5]) + cst, true,
+      const double floor_c = (1.0 + 1.0 / mu) * (safety * est) * (safety * est);
+      const double cst = (floor_c + safety * k1 * en1) / (1.0 - safety * kn) * 1.0001;
+      // The outcome is produced as clamp(N - s^2), exactly 0 or 1 (see eh_upper_mfma2_kernel: the hypothesis is scaled by a power of
+      // two lambda with lambda^2 floor_c >= 2^50), and the outcomes of a row are gathered with acc = 2 acc + outcome, both
+      // full-rate instructions (a v_alignbit per pair costs two issue slots).  Where that scale would leave float32's range,
+      // or the threshold lies outside the range the argument covers, every pair of the hypothesis counts as passing.
+      int ex = 0;
+      (void)frexp(floor_c, &ex);  // floor_c >= 2^(ex - 1)
+      int lg = (52 - ex) / 2;
+      if (2 * lg < 51 - ex) ++lg;
+      if (!(floor_c > 0.0) || lg > 58 || lg < -30 || !(k > 0x1.0p-45 && k < 0.55)) {
+        early_all_own = 0xFFFFu;
+        lg = 0;
+      }
+      elam = ldexp(1.0, lg);
+      const double l2 = elam * elam * k1;
+      pack_form(l2 * fma(e[0], e[0], e[3] * e[3]), 2.0 * l2 * fma(e[0], e[1], e[3] * e[4]), l2 * fma(e[1], e[1], e[4] * e[4]),
+                2.0 * l2 * fma(e[0], e[2], e[3] * e[5]), 2.0 * l2 * fma(e[1], e[2], e[4] * e[5]), l2 * fma(e[2], e[2], e[5] * e[5]) + elam * elam * cst, true,
                 bstage[lane][2][0], bstage[lane][2][1]);
     }
     fetch_round(BE, 3, kEarly ? 3 : 2);
     if constexpr (kEarly) {  // third staging pass: the two vectors of the early test's s
-      const double c1[5] = {e[0], e[1], e[3], e[4], e[2]}, c2[4] = {e[5], e[6], e[7], e[8]};
+      const double c1[5] = {e[0] * elam, e[1] * elam, e[3] * elam, e[4] * elam, e[2] * elam}, c2[4] = {e[5] * elam, e[6] * elam, e[7] * elam, e[8] * elam};
       pack_tri<5>(c1, true, bstage[lane][0][0], bstage[lane][0][1]);
       pack_tri<4>(c2, true, bstage[lane][1][0], bstage[lane][1][1]);
       fetch_round(BT, 0, 2);
@@ -1583,6 +1600,9 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     eb[k] = __shfl(eb_own, 32 * k + col);
     gh[k] = __shfl(gh_own, 32 * k + col);
   }
+  unsigned early_all[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) early_all[k] = (unsigned)__shfl((int)early_all_own, 32 * k + col);
   qcnt[wave][0][lane] = 0;
   if constexpr (kDoE && kDoH) qcnt[wave][1][lane] = 0;
   // The one-model instantiations (E at three, H at four waves per SIMD) are a dozen registers short: three (E) or four (H) piece vectors
@@ -1741,9 +1761,11 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
           const f32x16 nv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AN1, BE[k][kDoE ? 5 : 0], zero, 0, 0, 0);
           sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT2, BT[k][(kDoE && kEarly) ? 1 : 0], sv, 0, 0, 0);
           if (k == 1) load_early(src);
+          float acc = 0.0f;  // the outcomes of the row as a binary number: bit 15 - i = pair i (exact: below 2^16)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) hp = __builtin_amdgcn_alignbit(hp, __float_as_uint(fma(sv[i], sv[i], -nv[i])), 31);  // < 0 <=> passes
-          pass[k] = (hp | force_f64) & vmask;
+          for (int i = 0; i < 16; ++i) acc = fma(acc, 2.0f, __builtin_amdgcn_fmed3f(fma(-sv[i], sv[i], nv[i]), 0.0f, 1.0f));  // 1 <=> passes
+          hp = (unsigned)acc;
+          pass[k] = (hp | force_f64 | early_all[k]) & vmask;
         } else {
           int at = lane;
           asm volatile("" : "+v"(at));

@@ -126,6 +126,21 @@ def test_matrix_core_bounds_across_coordinate_scales_and_thresholds(env):
         assert wE == (int(ce_h.max()), int(np.argmax(ce_h))) and wH == (int(ch_h.max()), int(np.argmax(ch_h))), name
 
 
+def test_exact_counts_at_extreme_thresholds(env, mixed_form):
+    """Thresholds outside the range in which the early loop can produce its test outcome exactly (2 thr^2 at or above 0.55, or
+    below 2^-45) and at the edges of that range: every pair of such a hypothesis goes to the float64 queue or the wave goes
+    over to the full tests; the counts stay those of the float64 kernel."""
+    torch, C, ops = env
+    n, B = 1500, 6000
+    sc, x1, x2 = scene(n, inl=0.5, seed=31)
+    corr = C.dev(ops.pack_corr(x1, x2))
+    idx = C.dev(np.random.default_rng(9).integers(0, n, (B, 12)), np.int32)
+    for thr in (0.9, 0.53, 0.5, 4.0e-7, 3.0e-7, 1.0e-8, 1.0e-12):
+        ce, ch = ops.eh_score(corr, idx, thr, 3 * thr)
+        me, mh = ops.eh_score_mixed(corr, idx, thr, 3 * thr)
+        assert torch.equal(ce, me) and torch.equal(ch, mh), thr
+
+
 def test_non_positive_thresholds_follow_the_reference(env):
     """thr_h <= 0 and the reprojection threshold <= 0 admit nothing (the reference compares a norm with them); a
     negative epipolar threshold behaves like its absolute value (the reference squares it)."""
