@@ -1471,6 +1471,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   unsigned early_all_own = 0u;  // 0xFFFF: every pair of this hypothesis passes the early test (its outcome cannot be produced exactly)
   bf16x8 BE[2][kDoE ? 6 : 1], BH[2][kDoH ? 3 : 1];  // BE[.][5]: the form of the early test
   bf16x8 BT[2][(kDoE && kEarly) ? 2 : 1];           // the early test's s: three piece products per monomial in two vectors
+  bf16x8 BHe[2][(kDoH && kEarly) ? 3 : 1];          // the early test of the H launch: dx in two vectors, the form of (rt hz)^2 + c
   {
     double p8[8][4], p4[4][4];
     gather_samples<double>(corr, n, idx + 12 * hyp, p8, p4);
@@ -1592,6 +1593,39 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
 #pragma unroll
     for (int v = 1; v < 3; ++v) pack_pieces(Hd[3 * v] * inv, Hd[3 * v + 1] * inv, Hd[3 * v + 2] * inv, true, bstage[lane][v][0], bstage[lane][v][1]);
     fetch_round(BH, 0, 3);
+    if constexpr (kEarly) {
+      // The early test: dx^2 + dy^2 < T hz^2 implies dx^2 < T hz^2.  dx = x2 hz - hx is a bilinear form in the monomials of the
+      // vectors T1, T2 (two chained MFMAs, three piece products each) and T hz^2 a quadratic form in x1 (vector N1): the same
+      // shape as the early test of the E launch, with the same slack algebra (|dx_c - dx| <= ed, AM-GM with mu, the form's own
+      // error eq) and the same exact 0 / 1 outcome under a power-of-two scale of the hypothesis.
+      double h[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) h[i] = Hd[i] * inv;
+      const double u = kEps32, kn = 3.1 * 0x1.0p-18 + 34.0 * u;
+      const double TA = xm * xm * (A[6] + A[7]) + xm * A[8], TB = xm * (A[0] + A[1]) + A[2];
+      const double ed = (3.1 * 0x1.0p-18 / u * (TA + TB) + 32.0 * (1.0 + 0x1.0p-5) * (2.0 * TA + TB)) * u;
+      const double hz_ref = sqrt(A[8] * A[8] + xm * xm / 3.0 * (A[6] * A[6] + A[7] * A[7]));
+      const double mu = fmin(0.5, fmax(0x1.0p-7, safety * ed / (rt * hz_ref)));
+      const double T1 = thr_h2 * (1.0 + mu) * (1.0 + 32.0 * kEps32);
+      const double eq = (kn * T1 * R2 * R2 + 0x1.02p-9 * xm * xm * fabs(2.0 * T1 * h[6] * h[7])) * 1.0001;
+      const double floor_c = (1.0 + 1.0 / mu) * (safety * ed) * (safety * ed);
+      const double cst = (floor_c + safety * eq) / (1.0 - safety * kn) * 1.0001;
+      int ex = 0;
+      (void)frexp(floor_c, &ex);  // floor_c >= 2^(ex - 1)
+      int lg = (52 - ex) / 2;
+      if (2 * lg < 51 - ex) ++lg;
+      if (!(floor_c > 0.0) || lg > 58 || lg < -30 || !(thr_h2 > 0x1.0p-45 && thr_h2 < 0.5) || !(xm < 1.0e5)) {
+        early_all_own = 0xFFFFu;
+        lg = 0;
+      }
+      const double lam = ldexp(1.0, lg), l2 = lam * lam * T1;
+      const double c1[5] = {h[6] * lam, h[7] * lam, 0.0, 0.0, h[8] * lam}, c2[4] = {0.0, -h[0] * lam, -h[1] * lam, -h[2] * lam};
+      pack_tri<5>(c1, true, bstage[lane][0][0], bstage[lane][0][1]);
+      pack_tri<4>(c2, true, bstage[lane][1][0], bstage[lane][1][1]);
+      pack_form(l2 * h[6] * h[6], 2.0 * l2 * h[6] * h[7], l2 * h[7] * h[7], 2.0 * l2 * h[6] * h[8], 2.0 * l2 * h[7] * h[8],
+                l2 * h[8] * h[8] + lam * lam * cst, true, bstage[lane][2][0], bstage[lane][2][1]);
+      fetch_round(BHe, 0, 3);
+    }
   }
   float ea[2], eb[2], gh[2];
 #pragma unroll
@@ -1721,7 +1755,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     AN1 = as_bf16x8(q[2 * 64]);
   };
   if (t0 < t1) {
-    if constexpr (kDoE && kPark && kEarly)
+    if constexpr (kPark && kEarly)
       load_early(src);
     else
       load_tile(src);
@@ -1744,14 +1778,6 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
       const unsigned vmask = tail_mask | fill;
       const bool more = t + 1 < t1;
       if (more) src += kEhxVecA * 64;
-      float x2[kDoH ? 16 : 1];  // (reloading each register for the next tile right after its last use was measured: 1 % slower)
-      if constexpr (kDoH) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float4 v = xsrc[i];
-          x2[2 * i] = v.x; x2[2 * i + 1] = v.z;
-        }
-      }
       unsigned pass[2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -1767,26 +1793,20 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
           hp = (unsigned)acc;
           pass[k] = (hp | force_f64 | early_all[k]) & vmask;
         } else {
-          int at = lane;
-          asm volatile("" : "+v"(at));
-          const bf16x8 h0 = k == 1 ? as_bf16x8(parked[at]) : BH[k][0];
-          const bf16x8 h2 = as_bf16x8(parked[(k == 1 ? 128 : 192) + at]);
-          const f32x16 hx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, h0, zero, 0, 0, 0);
-          const f32x16 hz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, h2, zero, 0, 0, 0);
-          if (k == 1) load_tile(src);
+          f32x16 sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT1, BHe[k][0], zero, 0, 0, 0);  // dx
+          const f32x16 nv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AN1, BHe[k][(kDoH && kEarly) ? 2 : 0], zero, 0, 0, 0);  // (rt hz)^2 + c
+          sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AT2, BHe[k][(kDoH && kEarly) ? 1 : 0], sv, 0, 0, 0);
+          if (k == 1) load_early(src);
+          float acc = 0.0f;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const float P = fma(x2[i], hz[i], -hx[i]);
-            const float M = fma(two_rt, hz[i], P);
-            hp = __builtin_amdgcn_alignbit(hp, __float_as_uint(fma(P, M, -gh[k])), 31);  // < 0 <=> passes
-          }
-          pass[k] = (hp | force_h) & vmask;
+          for (int i = 0; i < 16; ++i) acc = fma(acc, 2.0f, __builtin_amdgcn_fmed3f(fma(-sv[i], sv[i], nv[i]), 0.0f, 1.0f));  // 1 <=> passes
+          hp = (unsigned)acc;
+          pass[k] = (hp | force_h | early_all[k]) & vmask;
         }
       }
       const unsigned long long any0 = ballot64(pass[0] != 0u), any1 = ballot64(pass[1] != 0u);
       if (__popcll(any0) + __popcll(any1) > kDenseRows) {
         if (more) src -= kEhxVecA * 64;  // this tile again (the next one was on its way)
-        if constexpr (!kDoE) load_tile(src);
         break;
       }
       const int before = qtot;
@@ -1797,8 +1817,8 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
         break;
       }
     }
+    if (t < t1) load_tile(src);  // the early loop only ever loaded its own three vectors of a tile
     if constexpr (kDoE) {  // the vectors of k n1 and n2 come back for the full tests (unconditionally: they are dead inside the early loop)
-      if (t < t1) load_tile(src);  // the early loop only ever loaded its own three vectors of a tile
       int at = lane;
       asm volatile("" : "+v"(at));
 #pragma unroll
