@@ -1290,8 +1290,8 @@ def main():
             "exact_counts_early_out": {
                 "what": "the library's default form of the exact step (sfm_eh_score_mixed + sfm_argmax_count_i32, what estimate_E_robust's block "
                 "scoring calls): the float64 inlier counts of EVERY hypothesis, identical to the headline step's, but a pair that fails a cheaper "
-                "implied test -- the one-sided epipolar test s^2 < k1 n1 + c (4 matrix + 3 vector issue slots per pair instead of 5 + 10), the x "
-                "part (dx - q)(dx + q) < g of the disc test (2 + 5 instead of 3 + 8) -- is proven to be no float64 inlier and skips the full "
+                "implied test -- the one-sided epipolar test s^2 < k1 n1 + c (3 MFMAs per 32 x 32 pairs + 2 vector issue slots per pair instead of "
+                "5 + 10), the x strip dx^2 < (rt hz)^2 + c of the disc test (3 + 2 instead of 3 + 8) -- is proven to be no float64 inlier and skips the full "
                 "test; the few pairs per thousand that pass take the float64 test.  Pairs decided per second, NOT `value`: most pairs do not go "
                 "through the reference's full residual arithmetic, so its algorithmic rate may exceed the vector peak",
                 "kernel_ms": early_ms,

@@ -1762,11 +1762,13 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
   }
   int t = t0;
   // EARLY LOOP (one-model instantiations).  Each test is implied by a cheaper one whose failure proves a pair to be no float64
-  // inlier: the symmetric epipolar test by the one-sided s^2 < k1 n1 + c of eh_upper_mfma2_kernel (four MFMAs and three
-  // issue slots per pair instead of five and ten), the disc test dx^2 + dy^2 < q^2 by its x part (dx - q)(dx + q) < gh (two
-  // MFMAs and five slots instead of three and eight; gh >= 4 Q e + e^2 covers the computed product of a true inlier, whose
-  // |dx| is below |q| <= Q).  The pairs that pass (a few per thousand for most hypotheses) go straight to the float64 queue;
-  // nothing else is counted here.  The queue costs about eight issue cycles per pair, the early loop saves 500 (E) / 250 (H)
+  // inlier: the symmetric epipolar test by the one-sided s^2 < k1 n1 + c of eh_upper_mfma2_kernel, the disc test
+  // dx^2 + dy^2 < q^2 by its x strip dx^2 < (rt hz)^2 + c.  Either runs as three MFMAs (the left side's root from two chained
+  // ones, the whole right side as one quadratic form with the slack in its constant term) and two issue slots per pair (the
+  // outcome clamp(right - left^2), exactly 0 or 1 under the power-of-two scale of the hypothesis, and the gather
+  // acc = 2 acc + outcome) instead of five MFMAs and ten slots (E) / three and eight (H).  The pairs that pass (a few per
+  // thousand for most hypotheses) go straight to the float64 queue;
+  // nothing else is counted here.  The queue costs about eight issue cycles per pair, the early loop saves 500 (E) / 350 (H)
   // per tile of 2048 pairs: a wave with several hypotheses from all-inlier samples is better off with the full float32
   // tests below.  It goes over to them for good when a tile has queued more than kDensePairs pairs, and at once (reloading
   // the tile it is on) when more than kDenseRows of the tile's 128 sixteen-pair rows hold a passing pair.
