@@ -113,7 +113,7 @@ int sfm_eh_best(const double* corr, const float* corr32, int32_t n, const int32_
  * re-evaluated with the float64 test inside the kernel (queued per wave, 64 pairs at a time).
  * Early loops (default): each test is implied by a cheaper one -- the symmetric epipolar test of src/ransac_algorithm.py:98-102
  * by its one-sided half (distance to the epipolar line in the second view alone, widened by the rigorous error band), the
- * disc test of :120-121, :320-327 by its x component -- and a pair that fails the cheaper test is proven to be no float64
+ * disc test of :120-121, :320-327 by its x strip (|dx| below the radius) -- and a pair that fails the cheaper test is proven to be no float64
  * inlier without the full test; the few pairs per thousand that pass take the float64 test.  A wave whose hypotheses come from
  * all-inlier samples (most pairs pass) goes over to the full float32 tests.  The counts are the same either way.
  * sfm_eh_score_mixed_opt: options = SFM_EHX_EVERY_PAIR_FULL_TEST sends EVERY pair through the full symmetric-epipolar and
