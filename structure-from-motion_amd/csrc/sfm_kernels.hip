@@ -1841,6 +1841,7 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
         x2[2 * i] = v.x; y2[2 * i] = v.y; x2[2 * i + 1] = v.z; y2[2 * i + 1] = v.w;
       }
     }
+    unsigned both_e = 0, both_h = 0;  // bits 0-15: group 0, bits 16-31: group 1
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       unsigned amb_e = 0, amb_h = 0;
@@ -1921,12 +1922,15 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
         }
       }
       SFM_STAMP_COUNT((amb_e | amb_h) != 0u);
-      if constexpr (kDoE) {
-        if (const unsigned long long any = ballot64(amb_e != 0u)) enqueue(amb_e, any, 32 * k + col, 0, t * 32 + 16 * half);
-      }
-      if constexpr (kDoH) {
-        if (const unsigned long long any = ballot64(amb_h != 0u)) enqueue(amb_h, any, 32 * k + col, 1, t * 32 + 16 * half);
-      }
+      both_e |= amb_e << (16 * k);
+      both_h |= amb_h << (16 * k);
+    }
+    // the pairs inside a band of both hypothesis groups are queued in one pass per tile and test
+    if constexpr (kDoE) {
+      if (const unsigned long long any = ballot64(both_e != 0u)) enqueue2(both_e, any, 0, t * 32 + 16 * half);
+    }
+    if constexpr (kDoH) {
+      if (const unsigned long long any = ballot64(both_h != 0u)) enqueue2(both_h, any, 1, t * 32 + 16 * half);
     }
   }
   drain();
