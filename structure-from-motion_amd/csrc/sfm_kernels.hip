@@ -1702,23 +1702,9 @@ __global__ __launch_bounds__(kBlock, kMinBlocks) void eh_score_mfma2_kernel(cons
     qlen = 0;
     __builtin_amdgcn_wave_barrier();
   };
-  // called by the whole wave with any = the lanes that have a pair to queue (not empty); bit 15-i of amb = match first_match + i
-  auto enqueue = [&](unsigned amb, unsigned long long any, int hyp_of_wave, int test_h, int first_match) {
-    do {
-      const bool act = amb != 0u;
-      const int bit = __ffs((int)amb) - 1;
-      amb &= amb - 1u;
-      const unsigned entry = ((unsigned)(first_match + 15 - bit) << 7) | ((unsigned)test_h << 6) | (unsigned)hyp_of_wave;
-      const int pos = qlen + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(any >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)any, 0u));
-      if (act) qbuf[wave][pos] = entry;
-      qlen += __popcll(any);
-      qtot += __popcll(any);
-      if (qlen > kQueue - 64) drain();
-      any = ballot64(amb != 0u);
-    } while (any);
-  };
-  // the same for both hypothesis groups of a tile in one pass (the early loops: nearly every tile has a pair to queue in either
-  // group, and a pass costs as much for one group as for two): bits 0-15 of `both` = group 0, bits 16-31 = group 1
+  // Called by the whole wave with any = the lanes that have a pair to queue (not empty).  Both hypothesis groups of a tile go in
+  // one pass (a pass costs as much for one group as for two): bits 0-15 of `both` = group 0, bits 16-31 = group 1, bit 15 - i of
+  // either half = match first_match + i.  One entry per lane and round, so a pass takes as many rounds as the fullest lane has pairs.
   auto enqueue2 = [&](unsigned both, unsigned long long any, int test_h, int first_match) {
     do {
       const bool act = both != 0u;
